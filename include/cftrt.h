@@ -1,0 +1,184 @@
+/* cftrt.h — C ABI of libcftrt.so: the MI355X (gfx950) trace loop for the cft_ray_tracer scene API.
+ *
+ * The reference crate (cfeitong/ray-tracing) has NO FFI and no batched render entry point: its
+ * examples hand-roll the render loop around the per-ray API
+ *     Camera::emit_rays  (src/ray.rs:107-136)
+ *     World::trace       (src/object.rs:326-355)
+ *     Ray::hit           (src/ray.rs:18-28)
+ *     accumulate/resolve (examples/scene.rs:82-127, examples/cornell.rs:31-57)
+ * This header is the boundary a façade's `World::render(&Camera, w, h, depth)` binds to
+ * (INTEGRATION.md shows the Rust `extern "C"` block).  Plain pointers and sizes only; every
+ * function returns a status code and never aborts or throws across the boundary (the reference
+ * panics on `unwrap`; SURVEY.md §8b "Errors").
+ *
+ * Ownership: the caller owns every host buffer; `cftrt_scene_set_*` copy; handles are freed only
+ * by `*_destroy`.  Threading: a ctx is bound to one device and one stream and is NOT thread-safe;
+ * use one ctx (one host thread / one process) per GPU.  Scenes are immutable after commit.
+ */
+#ifndef CFTRT_H
+#define CFTRT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CFTRT_OK 0
+#define CFTRT_ERR_INVALID 1   /* bad argument (null pointer, negative size, ids out of range) */
+#define CFTRT_ERR_HIP 2       /* a HIP runtime call failed; text in cftrt_last_error */
+#define CFTRT_ERR_STATE 3     /* call out of order (render before commit, set after commit) */
+#define CFTRT_ERR_LIMIT 4     /* size beyond a documented limit */
+
+typedef struct cftrt_ctx cftrt_ctx;
+typedef struct cftrt_scene cftrt_scene;
+
+/* Material table row.  Replaces the `Arc<dyn Material>` trait objects:
+ *   kind 0 LambertianModel  p0=albedo              color   (src/material/compose.rs:90-119)
+ *   kind 1 Metal            p0=fuzz  p1=albedo     color   (src/material/compose.rs:9-52)
+ *   kind 2 Dielectric       p0=ior                         (src/material/compose.rs:54-88)
+ *   kind 3 PhongModel       p0=shininess p1=diffuse color  (src/material/basic.rs:10-98)
+ *   kind 4 Specular         p0=albedo                      (src/material/basic.rs:100-124)
+ *   kind 5 Transparent      p0=opacity p1=ior      color   (src/material/basic.rs:126-184) */
+typedef struct cftrt_material {
+  int32_t kind;
+  int32_t reserved;
+  double p0, p1;
+  double color[3];
+} cftrt_material;
+
+#define CFTRT_MAT_LAMBERTIAN 0
+#define CFTRT_MAT_METAL 1
+#define CFTRT_MAT_DIELECTRIC 2
+#define CFTRT_MAT_PHONG 3
+#define CFTRT_MAT_SPECULAR 4
+#define CFTRT_MAT_TRANSPARENT 5
+
+/* Light list row.  Replaces `Arc<dyn LightSource>` (src/light.rs):
+ *   kind 0 SkyLight                                   (light.rs:151-191)
+ *   kind 1 LightShape: shape = light spheres [sph_begin, sph_begin+sph_count) and light
+ *          triangles [tri_begin, tri_begin+tri_count), Square/Cube pre-expanded in the
+ *          reference's face/triangle order; color fixed (1,1,1)   (light.rs:193-243)
+ *   kind 2 PointLight    v=pos, color                 (light.rs:104-149)
+ *   kind 3 ParallelLight v=dir (used un-normalised), color  (light.rs:66-102) */
+typedef struct cftrt_light {
+  int32_t kind;
+  int32_t sph_begin, sph_count;
+  int32_t tri_begin, tri_count;
+  int32_t reserved;
+  double v[3];
+  double color[3];
+} cftrt_light;
+
+#define CFTRT_LIGHT_SKY 0
+#define CFTRT_LIGHT_SHAPE 1
+#define CFTRT_LIGHT_POINT 2
+#define CFTRT_LIGHT_PARALLEL 3
+
+/* Camera POD: the state `Camera::new(from,to).with_*()` leaves behind (src/ray.rs:46-104,139-152).
+ * `up` and `sight` are the values stored after `look()`; right = unit(sight x up) is derived. */
+typedef struct cftrt_camera {
+  double pos[3];
+  double up[3];
+  double sight[3];
+  double focus_dist;
+  double aperture;
+  double fov_rad; /* radians; the reference's default is 45 *radians* (ray.rs:147) */
+  double aspect;
+} cftrt_camera;
+
+#define CFTRT_MAX_LEVELS 256
+
+/* Filled by the render calls.  "Rays" follow BASELINE.md §2: every trace() level with depth>0
+ * plus one ray per (Phong hit, light). */
+typedef struct cftrt_stats {
+  uint64_t paths;             /* primary samples rendered */
+  uint64_t rays;              /* all bounces (+ Phong light rays) */
+  uint64_t phong_rays;        /* subset of `rays` issued by the shadow kernel */
+  uint64_t exact_second;      /* rays whose runner-up candidate needed an f64 evaluation */
+  uint64_t exact_rescan;      /* rays that fell back to the full f64 scan */
+  double flops;               /* algorithmic: sum over rays of 16*Nsph + 44*Ntri + 200 */
+  double flops_intersect;     /* part of `flops` done by the intersect kernel: rays*(16 Nsph+44 Ntri) */
+  double ms_total;            /* wall time of the call's device work (HIP events) */
+  double ms_generate, ms_intersect, ms_shade, ms_shadow, ms_resolve;
+  uint32_t launches_intersect;
+  uint32_t levels;            /* trace levels that had at least one ray */
+  uint32_t passes;
+  uint32_t reserved;
+  uint64_t rays_per_level[CFTRT_MAX_LEVELS];
+} cftrt_stats;
+
+/* ---- context ---------------------------------------------------------------------------- */
+int cftrt_device_count(int* out_n);
+int cftrt_ctx_create(int device, cftrt_ctx** out);
+void cftrt_ctx_destroy(cftrt_ctx* ctx);
+/* Last error text of this ctx (or of the failed create when ctx is NULL). Never NULL. */
+const char* cftrt_last_error(const cftrt_ctx* ctx);
+/* Cap on the path workspace (bytes of HBM the render calls may hold; default 40 GiB). */
+int cftrt_ctx_set_workspace_limit(cftrt_ctx* ctx, uint64_t bytes);
+/* Intersect-kernel variant: 0 = primitives via scalar (SGPR) loads, 1 = LDS-staged tiles. */
+int cftrt_ctx_set_variant(cftrt_ctx* ctx, int variant);
+
+/* ---- scene (replaces World::empty/add_obj/add_light, src/object.rs:311-324) ------------- */
+int cftrt_scene_create(cftrt_ctx* ctx, cftrt_scene** out);
+void cftrt_scene_destroy(cftrt_scene* scene);
+/* Spheres (src/object.rs:257-303).  center: n x 3, radius: n (negative flips the normal),
+ * moving_to: n x 3 or NULL (Object::moved, object.rs:37-40), obj_id: index of the owning object in
+ * world.objects (non-decreasing), mat_id: row of the material table. */
+int cftrt_scene_set_spheres(cftrt_scene* scene, const double* center, const double* radius,
+                            const double* moving_to, const int32_t* obj_id, const int32_t* mat_id,
+                            int64_t n);
+/* Triangles (src/object.rs:58-139); Square = 2 and Cube = 12 triangles sharing one obj_id, expanded
+ * by the host in the reference's order (object.rs:147-162, 215-230).  p0,p1,p2: n x 3 each. */
+int cftrt_scene_set_triangles(cftrt_scene* scene, const double* p0, const double* p1,
+                              const double* p2, const double* moving_to, const int32_t* obj_id,
+                              const int32_t* mat_id, int64_t n);
+int cftrt_scene_set_materials(cftrt_scene* scene, const cftrt_material* table, int64_t n);
+int cftrt_scene_set_lights(cftrt_scene* scene, const cftrt_light* lights, int64_t n_lights,
+                           const double* lsph_center, const double* lsph_radius, int64_t n_lsph,
+                           const double* ltri_p0, const double* ltri_p1, const double* ltri_p2,
+                           int64_t n_ltri);
+/* Spheres with |radius| >= this are tested in f64 for every ray (default 25). */
+int cftrt_scene_set_precise_radius(cftrt_scene* scene, double radius);
+/* Uploads the flattened scene to HBM.  No setter may be called afterwards. */
+int cftrt_scene_commit(cftrt_scene* scene);
+
+/* ---- the hot path ------------------------------------------------------------------------ */
+/* Replaces the examples' render loop (scene.rs:91-102, cornell.rs:32-39):
+ *   accum[(h*W+w)*3 + c] += sum over samples s in [spp_begin, spp_end) of World::trace(ray, max_depth)
+ * accum is a caller-allocated HOST buffer of W*H*3 floats, row-major, h = 0 is the top row.
+ * The path id of (sample s, pixel h*W+w) is s*W*H + h*W + w and keys the Philox stream, so the
+ * result does not depend on how the sample range is split over calls or GPUs. */
+int cftrt_render(cftrt_scene* scene, const cftrt_camera* cam, uint32_t width, uint32_t height,
+                 uint32_t spp_begin, uint32_t spp_end, uint32_t max_depth, uint64_t seed,
+                 float* accum_host, cftrt_stats* stats);
+/* Same, accumulating into a DEVICE buffer (W*H*3 floats on the ctx's device), e.g. a torch tensor
+ * that is then reduced over ranks with RCCL.  The call returns after its stream has drained. */
+int cftrt_render_device(cftrt_scene* scene, const cftrt_camera* cam, uint32_t width,
+                        uint32_t height, uint32_t spp_begin, uint32_t spp_end, uint32_t max_depth,
+                        uint64_t seed, void* accum_device, cftrt_stats* stats);
+
+/* ---- parity hooks (one kernel each, host buffers) ------------------------------------------ */
+/* Camera::emit_rays for path ids [pid0, pid0+n): out_rays = n x 6 floats (pos, dir).
+ * jitter = 0 disables the pixel/lens draws (pixel centre, lens centre). */
+int cftrt_generate(cftrt_ctx* ctx, const cftrt_camera* cam, uint32_t width, uint32_t height,
+                   uint64_t pid0, uint64_t n, uint64_t seed, int jitter, float* out_rays);
+/* Ray::hit for caller-supplied rays (n x 6 floats, dir used as given).  out_id = object index or
+ * -1, out_t = distance (f64, the exact evaluation), out_normal = n x 3 shading normal after
+ * HitInfo::new's flip, out_point = n x 3 hit point.  Motion times are keyed by
+ * (seed, pid0+i, level, role) like the render path.  Any out_* except out_id may be NULL. */
+int cftrt_intersect(cftrt_scene* scene, const float* rays, uint64_t n, uint64_t seed,
+                    uint64_t pid0, uint32_t level, uint32_t role, int32_t* out_id, double* out_t,
+                    float* out_normal, float* out_point);
+/* World::trace per path: out_rgb = n x 3 floats for path ids [pid0, pid0+n). */
+int cftrt_trace_paths(cftrt_scene* scene, const cftrt_camera* cam, uint32_t width, uint32_t height,
+                      uint64_t pid0, uint64_t n, uint32_t max_depth, uint64_t seed, int jitter,
+                      float* out_rgb, cftrt_stats* stats);
+/* vec3_to_rgb (scene.rs:122-127): out[i] = trunc(255.99*sqrt(clamp(accum[i]/divisor, 0, 1))). */
+int cftrt_resolve_rgb8(cftrt_ctx* ctx, const float* accum_host, uint64_t npix, double divisor,
+                       uint8_t* out_rgb8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CFTRT_H */

@@ -1,0 +1,940 @@
+// oracle.cpp — CPU restatement (f64) of the per-pixel trace loop of cfeitong/ray-tracing.
+//
+// TEST INFRASTRUCTURE ONLY.  Nothing under ray-tracing_amd/ (the product) may link, import or
+// execute this file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+//
+// Why a restatement: the reference is Rust (nightly, crates.io deps) and there is no
+// rustc/cargo in this image, so the reference itself cannot be built or run.
+// Every function below follows the cited reference lines literally, in f64, with FP contraction
+// disabled at build time (-ffp-contract=off) because Rust never fuses a*b+c.
+//
+// Pinning: the reference's own tests (util.rs:440-500, object.rs:362-393) are replayed against
+// this file by tests/test_oracle_kat.py.  Everything the reference does not test (sphere hit,
+// HitInfo flip, refract, Schlick, materials, lights, camera, trace) is "parity unpinned" by the
+// reference and is pinned only by source-following plus the hand-derived vectors of SURVEY §8c.
+//
+// The one deliberate difference: the reference draws from an unseeded per-thread `thread_rng()`
+// (unreproducible by design).  Here every draw comes from Philox4x32-10 keyed by
+// (seed, path id, trace level, purpose) — the same schedule the GPU uses (DESIGN.md "RNG
+// schedule") — so a path can be compared 1:1.  Only the *distributions* are the reference's.
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <thread>
+#include <vector>
+#include <atomic>
+#include <limits>
+
+namespace orc {
+
+static const double EPS = 1e-3;                 // util.rs:10
+static const double PI = 3.14159265358979323846264338327950288;  // util.rs:11 (f64::consts::PI)
+static const double FRAC_PI_2 = 1.57079632679489661923132169163975144;
+
+// ---------------------------------------------------------------- Vec3 (util.rs:14-78, 87-293)
+struct V {
+  double x, y, z;
+};
+static inline V v3(double x, double y, double z) { return V{x, y, z}; }
+static inline double dot(V a, V b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // util.rs:28-30
+static inline V cross(V a, V b) {                                                  // util.rs:40-46
+  return V{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+static inline double len(V a) { return std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }  // :52-54
+static inline double len2(V a) { return a.x * a.x + a.y * a.y + a.z * a.z; }            // :56-58
+static inline V neg(V a) { return V{-a.x, -a.y, -a.z}; }
+static inline V add(V a, V b) { return V{a.x + b.x, a.y + b.y, a.z + b.z}; }
+static inline V sub(V a, V b) { return V{a.x - b.x, a.y - b.y, a.z - b.z}; }
+static inline V mul(V a, double s) { return V{a.x * s, a.y * s, a.z * s}; }   // Vec3*f64, f64*Vec3
+static inline V mulv(V a, V b) { return V{b.x * a.x, b.y * a.y, b.z * a.z}; } // util.rs:228-238
+static inline V divs(V a, double s) { return V{a.x / s, a.y / s, a.z / s}; }  // util.rs:249-260
+static inline V unit(V a) { return divs(a, len(a)); }                        // util.rs:48-50
+static inline V proj_to(V a, V rhs) {                                        // util.rs:60-63
+  V n = unit(rhs);
+  return mul(n, dot(a, n));
+}
+
+// ---------------------------------------------------------------- Philox4x32-10 (Salmon et al., SC'11)
+struct U4 {
+  uint32_t v[4];
+};
+static inline U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                               uint32_t k1) {
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return U4{{c0, c1, c2, c3}};
+}
+// 24-bit uniform in [0,1): exactly representable in f32 and f64, so GPU and oracle see the
+// same number (the reference's rand 0.6 uses 52/53 bits; only the distribution matters).
+static inline double u24(uint32_t w) { return (double)(w >> 8) * (1.0 / 16777216.0); }
+static inline uint32_t lowbias32(uint32_t x) {  // integer finaliser used to fan one Philox word
+  x ^= x >> 16; x *= 0x7feb352du;               // out into per-object motion times
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+
+// RNG schedule: counter = (pid_lo, pid_hi, level, purpose), key = seed.
+enum : uint32_t { PURPOSE_CAMERA = 0, PURPOSE_SCATTER = 1, PURPOSE_SCAN0 = 16 };
+static const uint32_t LEVEL_CAMERA = 0xFFFFFFFFu;
+
+struct PathCtx {
+  uint64_t pid;
+  uint32_t k0, k1;
+  uint64_t rays;  // trace() calls with depth>0 + Phong light rays (BASELINE.md §2 definition)
+  U4 draw(uint32_t level, uint32_t purpose) const {
+    return philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), level, purpose, k0, k1);
+  }
+};
+
+// util.rs:384-395 — NOT uniform in the ball: always on the surface, z >= 0.
+static inline V gen_point_in_sphere(double radius, double u_theta, double u_phi) {
+  double r = radius;
+  double theta = 0. + (2. * PI - 0.) * u_theta;
+  double phi = -FRAC_PI_2 + (FRAC_PI_2 - (-FRAC_PI_2)) * u_phi;
+  return v3(r * std::sin(phi) * std::cos(theta), r * std::sin(phi) * std::sin(theta),
+            r * std::cos(phi));
+}
+// util.rs:397-402 — half disk, not area-uniform.
+static inline V gen_point_in_disk(double radius, double u_theta, double u_r) {
+  double theta = PI * u_theta;
+  double r = u_r;
+  return mul(v3(std::cos(theta), std::sin(theta), 0.), radius * r);
+}
+
+// ---------------------------------------------------------------- Ray / HitInfo (ray.rs)
+struct Ray {
+  V pos, dir;
+};
+static inline Ray ray_new(V pos, V dir) { return Ray{pos, unit(dir)}; }  // ray.rs:30-35
+
+struct HitInfo {  // ray.rs:222-251
+  double distance;
+  V norm, hit_point, dir_in, dir_out;
+  bool outward;
+};
+static inline HitInfo hitinfo_new(double distance, V norm, V hit_point, V dir_in) {
+  norm = unit(norm);
+  dir_in = unit(dir_in);
+  bool outward;
+  if (dot(norm, dir_in) > -EPS) {
+    norm = neg(norm);
+    outward = true;
+  } else {
+    outward = false;
+  }
+  V dir_out = unit(sub(dir_in, mul(proj_to(dir_in, norm), 2.)));
+  return HitInfo{distance, norm, hit_point, dir_in, dir_out, outward};
+}
+static inline V hi_pos(const HitInfo& h) { return add(h.hit_point, mul(h.dir_out, EPS)); }  // :269-271
+static inline Ray hi_reflect(const HitInfo& h) { return Ray{hi_pos(h), h.dir_out}; }        // :284-289
+static inline bool hi_refract(const HitInfo& h, double ratio, Ray* out) {                   // :293-308
+  V uv = h.dir_in;
+  V n = h.norm;
+  double cos = dot(uv, n);
+  double discriminant = 1.0 - (ratio * ratio) * (1.0 - cos * cos);
+  if (discriminant > 0.0) {
+    V dir = sub(mul(sub(uv, mul(n, cos)), ratio), mul(n, std::sqrt(discriminant)));
+    *out = Ray{add(h.hit_point, mul(dir, EPS)), dir};
+    return true;
+  }
+  return false;
+}
+static inline double hi_reflect_prob(const HitInfo& h, double ior) {  // ray.rs:312-316 (r0 NOT squared)
+  double r0 = (1. - ior) / ((1. + ior) * (1. + ior));
+  double cos = std::fabs(dot(h.dir_in, h.norm));
+  double m = 1. - cos;
+  return r0 + (1. - r0) * (m * m * m * m * m);  // powi(5) by repeated multiplication
+}
+
+// ---------------------------------------------------------------- Shapes (object.rs)
+struct Shape {
+  virtual ~Shape() {}
+  virtual bool hit_info(const Ray& ray, HitInfo* out) const = 0;
+  virtual bool hit_moving(const Ray& ray, V delta, HitInfo* out) const = 0;
+};
+
+struct Triangle : Shape {  // object.rs:58-139
+  V p0, p1, p2;
+  Triangle(V a, V b, V c) : p0(a), p1(b), p2(c) {}
+  V normal() const { return unit(cross(sub(p1, p0), sub(p2, p0))); }
+  bool is_in_plane(V point) const {  // :79-82
+    V v = sub(p0, point);
+    return std::fabs(dot(v, normal())) < EPS;
+  }
+  bool contain(V point) const {  // :84-96
+    if (!is_in_plane(point)) return false;
+    V pp0 = sub(p0, point), pp1 = sub(p1, point), pp2 = sub(p2, point);
+    V t0 = cross(pp0, pp1), t1 = cross(pp1, pp2), t2 = cross(pp2, pp0);
+    return dot(t0, t1) > -EPS && dot(t1, t2) > -EPS;
+  }
+  bool hit_info(const Ray& ray, HitInfo* out) const override {  // :100-130
+    V e1 = sub(p1, p0);
+    V e2 = sub(p2, p0);
+    V h = cross(ray.dir, e2);
+    double a = dot(e1, h);
+    if (-EPS < a && a < EPS) return false;
+    double f = 1. / a;
+    V s = sub(ray.pos, p0);
+    double u = f * dot(s, h);
+    if (u < 0. || u > 1.) return false;
+    V q = cross(s, e1);
+    double v = f * dot(ray.dir, q);
+    if (v < 0. || u + v > 1.) return false;
+    double t = f * dot(e2, q);
+    if (t > EPS) {
+      *out = hitinfo_new(t, unit(cross(e1, e2)), add(mul(ray.dir, t), ray.pos), ray.dir);
+      return true;
+    }
+    return false;
+  }
+  bool hit_moving(const Ray& ray, V delta, HitInfo* out) const override {  // :132-138
+    Triangle tri(add(p0, delta), add(p1, delta), add(p2, delta));
+    return tri.hit_info(ray, out);
+  }
+};
+
+struct Square : Shape {  // object.rs:141-197
+  Triangle tri0, tri1;
+  Square(Triangle a, Triangle b) : tri0(a), tri1(b) {}
+  static Square make(V center, V x, V y, double len_) {  // :148-162
+    V x2 = divs(mul(x, len_), 2.);
+    V y2 = divs(mul(y, len_), 2.);
+    V p0 = add(sub(center, x2), y2);
+    V p1 = sub(sub(center, x2), y2);
+    V p2 = sub(add(center, x2), y2);
+    V p3 = add(add(center, x2), y2);
+    return Square(Triangle(p0, p1, p2), Triangle(p2, p3, p0));
+  }
+  bool hit_info(const Ray& ray, HitInfo* out) const override {  // :191-193 tri0.or(tri1)
+    HitInfo a, b;
+    bool ha = tri0.hit_info(ray, &a);
+    bool hb = tri1.hit_info(ray, &b);
+    if (ha) { *out = a; return true; }
+    if (hb) { *out = b; return true; }
+    return false;
+  }
+  bool hit_moving(const Ray& ray, V delta, HitInfo* out) const override {  // :194-196
+    HitInfo a, b;
+    bool ha = tri0.hit_moving(ray, delta, &a);
+    bool hb = tri1.hit_moving(ray, delta, &b);
+    if (ha) { *out = a; return true; }
+    if (hb) { *out = b; return true; }
+    return false;
+  }
+};
+
+struct Cube : Shape {  // object.rs:199-255
+  V center, x, y;
+  double len_;
+  Cube(V c, V x_, V y_, double l) : center(c), x(x_), y(y_), len_(l) {}
+  std::vector<Square> squares() const {  // :215-230 (rebuilt per call in the reference)
+    V xx = unit(x);
+    V yy = unit(y);
+    V zz = unit(cross(xx, yy));
+    V c = center;
+    double l = len_;
+    std::vector<Square> r;
+    r.push_back(Square::make(add(c, mul(xx, l / 2.)), yy, zz, l));
+    r.push_back(Square::make(sub(c, mul(xx, l / 2.)), neg(yy), zz, l));
+    r.push_back(Square::make(add(c, mul(yy, l / 2.)), neg(xx), zz, l));
+    r.push_back(Square::make(sub(c, mul(yy, l / 2.)), xx, zz, l));
+    r.push_back(Square::make(add(c, mul(zz, l / 2.)), xx, yy, l));
+    r.push_back(Square::make(sub(c, mul(zz, l / 2.)), xx, neg(yy), l));
+    return r;
+  }
+  bool closest(const Ray& ray, V delta, bool moving, HitInfo* out) const {  // :234-254
+    bool any = false;
+    HitInfo best;
+    for (const Square& sq : squares()) {
+      HitInfo h;
+      bool ok = moving ? sq.hit_moving(ray, delta, &h) : sq.hit_info(ray, &h);
+      if (!ok) continue;
+      if (!any || h.distance < best.distance) {  // min_by: first minimum wins
+        best = h;
+        any = true;
+      }
+    }
+    if (any) *out = best;
+    return any;
+  }
+  bool hit_info(const Ray& ray, HitInfo* out) const override { return closest(ray, V{0, 0, 0}, false, out); }
+  bool hit_moving(const Ray& ray, V delta, HitInfo* out) const override { return closest(ray, delta, true, out); }
+};
+
+struct Sphere : Shape {  // object.rs:257-303
+  V center;
+  double radius;
+  Sphere(V c, double r) : center(c), radius(r) {}
+  bool hit_info(const Ray& ray, HitInfo* out) const override {  // :273-296
+    double a = len2(ray.dir);
+    double b = 2. * dot(sub(ray.pos, center), ray.dir);
+    double c = len2(sub(ray.pos, center)) - radius * radius;
+    double delta = b * b - 4. * a * c;
+    if (delta < 0.) return false;
+    double t1 = (-b - std::sqrt(delta)) / (2. * a);
+    double t2 = (-b + std::sqrt(delta)) / (2. * a);
+    if (t2 < 0.) return false;
+    double t = t1 < 0. ? t2 : t1;
+    V point = add(ray.pos, mul(ray.dir, t));
+    V norm = radius < 0. ? neg(unit(sub(point, center))) : unit(sub(point, center));
+    *out = hitinfo_new(t, norm, point, ray.dir);
+    return true;
+  }
+  bool hit_moving(const Ray& ray, V delta, HitInfo* out) const override {  // :298-302
+    Sphere s(add(center, delta), radius);
+    return s.hit_info(ray, out);
+  }
+};
+
+// ---------------------------------------------------------------- World, materials, lights
+struct World;
+struct Material {
+  virtual ~Material() {}
+  // scatter returns 0 or 1 rays for every built-in (material.rs:12-17)
+  virtual int scatter(const HitInfo& hit, PathCtx& ctx, uint32_t level, Ray* out) const {
+    *out = hi_reflect(hit);  // default: material.rs:14-16
+    return 1;
+  }
+  virtual V render(const HitInfo& hit, const World& world, const V* traced, PathCtx& ctx,
+                   uint32_t level) const = 0;
+};
+
+struct Object {  // object.rs:18-56
+  std::unique_ptr<Shape> shape;
+  int material;
+  V moving_to;
+};
+
+struct Light {
+  virtual ~Light() {}
+  virtual double intensity(const HitInfo& hit) const = 0;
+  virtual V dir_at(const HitInfo& hit) const = 0;
+  virtual V color(const HitInfo& hit) const = 0;
+  virtual bool is_in_shadow(const HitInfo& hit, const World& world, PathCtx& ctx, uint32_t level,
+                            uint32_t role) const;  // default light.rs:13-15
+  virtual bool looked(const Ray& ray, const World& world, PathCtx& ctx, uint32_t level,
+                      uint32_t role, V* out) const {  // default light.rs:17-19
+    return false;
+  }
+  virtual bool phong_uses_light_ray() const { return false; }
+};
+
+struct HitRecord {
+  int object;  // index into world.objects (the "object id" of the parity contract)
+  HitInfo info;
+};
+
+struct World {  // object.rs:305-356
+  std::vector<Object> objects;
+  std::vector<std::unique_ptr<Material>> materials;
+  std::vector<std::unique_ptr<Light>> lights;
+  bool any_motion = false;
+
+  // Ray::hit (ray.rs:18-28) + Object::hit_by (object.rs:42-55).  `role` numbers the scan inside
+  // one trace level so each scan draws its own motion time per object, as the reference does.
+  bool hit(const Ray& ray, PathCtx& ctx, uint32_t level, uint32_t role, HitRecord* out) const {
+    uint32_t word = 0;
+    if (any_motion) word = ctx.draw(level, PURPOSE_SCAN0 + role).v[0];
+    bool any = false;
+    HitRecord best;
+    for (size_t i = 0; i < objects.size(); ++i) {
+      const Object& o = objects[i];
+      double t = 0.;
+      if (o.moving_to.x != 0. || o.moving_to.y != 0. || o.moving_to.z != 0.)
+        t = u24(lowbias32(word ^ ((uint32_t)i * 0x9E3779B9u)));
+      V delta = mul(o.moving_to, t);  // t * moving_to (object.rs:45)
+      HitInfo h;
+      if (!o.shape->hit_moving(ray, delta, &h)) continue;
+      if (!any || h.distance < best.info.distance) {  // min_by: first minimum wins
+        best.object = (int)i;
+        best.info = h;
+        any = true;
+      }
+    }
+    if (any) *out = best;
+    return any;
+  }
+
+  uint32_t main_role() const { return (uint32_t)lights.size(); }
+
+  V trace(const Ray& ray, uint64_t depth, PathCtx& ctx, uint32_t level) const {  // object.rs:326-355
+    if (depth == 0) return v3(0., 0., 0.);
+    ctx.rays += 1;
+    bool see_light = false;
+    V color = v3(0., 0., 0.);
+    for (size_t i = 0; i < lights.size(); ++i) {
+      V c;
+      if (lights[i]->looked(ray, *this, ctx, level, (uint32_t)i, &c)) {
+        see_light = true;
+        color = add(color, c);
+      }
+    }
+    if (see_light) return color;
+    HitRecord hit;
+    if (!this->hit(ray, ctx, level, main_role(), &hit)) return v3(0., 0., 0.);
+    const Material& m = *materials[objects[hit.object].material];
+    Ray next;
+    V traced[1];
+    int n = m.scatter(hit.info, ctx, level, &next);
+    if (n == 1) traced[0] = trace(next, depth - 1, ctx, level + 1);
+    return m.render(hit.info, *this, traced, ctx, level);
+  }
+};
+
+bool Light::is_in_shadow(const HitInfo& hit, const World& world, PathCtx& ctx, uint32_t level,
+                         uint32_t role) const {
+  HitRecord r;
+  return world.hit(hi_reflect(hit), ctx, level, role, &r);
+}
+
+// material/basic.rs:100-124
+struct Specular : Material {
+  double albedo;
+  explicit Specular(double a) : albedo(a) {}
+  V render(const HitInfo&, const World&, const V* traced, PathCtx&, uint32_t) const override {
+    return mul(traced[0], albedo);
+  }
+};
+// material/basic.rs:126-184
+struct Transparent : Material {
+  double opacity, ior;
+  V color;
+  Transparent(double o, double i, V c) : opacity(o), ior(i), color(c) {}
+  V render(const HitInfo&, const World&, const V* traced, PathCtx&, uint32_t) const override {
+    return mulv(mul(color, 1. - opacity), traced[0]);
+  }
+  int scatter(const HitInfo& hit, PathCtx&, uint32_t, Ray* out) const override {
+    double n = hit.outward ? ior : 1. / ior;
+    if (!hi_refract(hit, n, out)) *out = hi_reflect(hit);  // total reflection
+    return 1;
+  }
+};
+// material/compose.rs:9-52
+struct Metal : Material {
+  double albedo, fuzz;
+  V color;
+  Metal(double f, double a, V c) : albedo(a), fuzz(f), color(c) {}
+  V render(const HitInfo&, const World&, const V* traced, PathCtx&, uint32_t) const override {
+    return mulv(mul(traced[0], albedo), color);
+  }
+  int scatter(const HitInfo& hit, PathCtx& ctx, uint32_t level, Ray* out) const override {
+    U4 w = ctx.draw(level, PURPOSE_SCATTER);
+    Ray r = hi_reflect(hit);
+    r.dir = unit(add(r.dir, gen_point_in_sphere(fuzz, u24(w.v[0]), u24(w.v[1]))));
+    *out = r;
+    return 1;
+  }
+};
+// material/compose.rs:54-88
+struct Dielectric : Material {
+  Transparent r;
+  explicit Dielectric(double ior) : r(0., ior, v3(1., 1., 1.)) {}
+  V render(const HitInfo& h, const World& w, const V* traced, PathCtx& c, uint32_t l) const override {
+    return r.render(h, w, traced, c, l);
+  }
+  int scatter(const HitInfo& hit, PathCtx& ctx, uint32_t level, Ray* out) const override {
+    U4 w = ctx.draw(level, PURPOSE_SCATTER);
+    if (u24(w.v[0]) < hi_reflect_prob(hit, r.ior)) {
+      *out = hi_reflect(hit);  // Specular::scatter = trait default
+      return 1;
+    }
+    return r.scatter(hit, ctx, level, out);
+  }
+};
+// material/compose.rs:90-119
+struct Lambertian : Material {
+  double albedo;
+  V c;
+  Lambertian(double a, V col) : albedo(a), c(col) {}
+  V render(const HitInfo&, const World&, const V* traced, PathCtx&, uint32_t) const override {
+    return mulv(c, mul(traced[0], albedo));
+  }
+  int scatter(const HitInfo& hit, PathCtx& ctx, uint32_t level, Ray* out) const override {
+    U4 w = ctx.draw(level, PURPOSE_SCATTER);
+    Ray r = hi_reflect(hit);
+    r.dir = unit(add(r.dir, gen_point_in_sphere(1., u24(w.v[0]), u24(w.v[1]))));
+    *out = r;
+    return 1;
+  }
+};
+// material/basic.rs:10-98 — terminal material, the only shadow-ray consumer.
+struct Phong : Material {
+  double shininess, diffuse;
+  V color;
+  Phong(double s, double d, V c) : shininess(s), diffuse(d), color(c) {}
+  int scatter(const HitInfo&, PathCtx&, uint32_t, Ray*) const override { return 0; }
+  V render(const HitInfo& hit, const World& world, const V*, PathCtx& ctx, uint32_t level) const override {
+    V c = v3(0., 0., 0.);
+    uint32_t nl = (uint32_t)world.lights.size();
+    for (uint32_t j = 0; j < nl; ++j) {
+      const Light& light = *world.lights[j];
+      ctx.rays += 1;  // one world-scanned ray per (Phong hit, light): reflect ray or light ray
+      V lc;
+      if (light.looked(hi_reflect(hit), world, ctx, level, nl + 1 + 2 * j, &lc)) {
+        c = add(c, lc);
+        continue;
+      }
+      V ldir = light.dir_at(hit);
+      double ratio2 = dot(hit.dir_out, neg(ldir));
+      double ratio = 1. * std::pow(ratio2, shininess);
+      ratio = (ratio < 1.) ? ratio : 1.;  // min!(ratio, 1.)  util.rs:369-380 (NaN -> 1)
+      ratio = (ratio > 0.) ? ratio : 0.;  // max!(ratio, 0.)
+      double si = ratio;
+      double dn = dot(hit.norm, neg(ldir));
+      double di = (dn > 0.) ? dn : 0.;  // max!(x, 0.)
+      double ai = 0.1;
+      V li = mul(light.color(hit), light.intensity(hit));
+      if (light.is_in_shadow(hit, world, ctx, level, nl + 2 + 2 * j))
+        c = add(c, mul(li, ai));
+      else
+        c = add(c, mul(li, si * 0.5 + di * 0.5 + ai));
+    }
+    return mulv(mul(c, diffuse), color);  // kd * c * self.color
+  }
+};
+
+// light.rs:66-102
+struct ParallelLight : Light {
+  V dir, light_color;
+  ParallelLight(V d, V c) : dir(d), light_color(c) {}
+  double intensity(const HitInfo&) const override { return 1.; }
+  V dir_at(const HitInfo&) const override { return dir; }
+  V color(const HitInfo&) const override { return light_color; }
+  bool is_in_shadow(const HitInfo& hit, const World& world, PathCtx& ctx, uint32_t level,
+                    uint32_t role) const override {
+    Ray ray = ray_new(hi_pos(hit), neg(dir_at(hit)));
+    HitRecord r;
+    return world.hit(ray, ctx, level, role, &r);
+  }
+};
+// light.rs:104-149
+struct PointLight : Light {
+  V pos, light_color;
+  PointLight(V p, V c) : pos(p), light_color(c) {}
+  double intensity(const HitInfo& hit) const override { return 1. / len2(sub(pos, hi_pos(hit))); }
+  V dir_at(const HitInfo& hit) const override { return unit(sub(hi_pos(hit), pos)); }
+  V color(const HitInfo&) const override { return light_color; }
+  bool is_in_shadow(const HitInfo& hit, const World& world, PathCtx& ctx, uint32_t level,
+                    uint32_t role) const override {
+    V point = hi_pos(hit);
+    Ray ray = ray_new(point, neg(dir_at(hit)));
+    HitRecord r;
+    if (!world.hit(ray, ctx, level, role, &r)) return false;
+    double l1 = len2(sub(point, r.info.hit_point));  // HitRecord::pos() is the un-offset point
+    double l2 = len2(sub(point, pos));
+    return l1 + EPS < l2;
+  }
+};
+// light.rs:151-191
+static inline V sky_color_from(V dir) {
+  double t = 0.5 * (dir.z + 1.0);
+  double v = 1.0 - t;
+  return add(mul(v3(1.0, 1.0, 1.0), v), mul(v3(0.5, 0.7, 1.0), t));
+}
+struct SkyLight : Light {
+  double intensity(const HitInfo&) const override { return 1.; }
+  V dir_at(const HitInfo& hit) const override { return neg(hit.dir_out); }
+  V color(const HitInfo& hit) const override { return sky_color_from(hit.dir_out); }
+  bool looked(const Ray& ray, const World& world, PathCtx& ctx, uint32_t level, uint32_t role,
+              V* out) const override {
+    HitRecord r;
+    if (!world.hit(ray, ctx, level, role, &r)) {
+      *out = sky_color_from(ray.dir);
+      return true;
+    }
+    return false;
+  }
+};
+// light.rs:193-243 — the light's own shape is tested static (hit_info, no motion).
+struct LightShape : Light {
+  std::unique_ptr<Shape> shape;
+  V col;
+  explicit LightShape(Shape* s) : shape(s), col(v3(1., 1., 1.)) {}
+  double intensity(const HitInfo& hit) const override {
+    HitInfo h;
+    return shape->hit_info(hi_reflect(hit), &h) ? 1. : 0.;
+  }
+  V dir_at(const HitInfo& hit) const override { return neg(hi_reflect(hit).dir); }
+  V color(const HitInfo&) const override { return col; }
+  bool is_in_shadow(const HitInfo& hit, const World& world, PathCtx& ctx, uint32_t level,
+                    uint32_t role) const override {
+    Ray r = hi_reflect(hit);
+    HitRecord ha;
+    bool a = world.hit(r, ctx, level, role, &ha);
+    HitInfo hb;
+    bool b = shape->hit_info(r, &hb);
+    return a && b && ha.info.distance < hb.distance;
+  }
+  bool looked(const Ray& ray, const World& world, PathCtx& ctx, uint32_t level, uint32_t role,
+              V* out) const override {
+    HitInfo info;
+    if (!shape->hit_info(ray, &info)) return false;
+    HitRecord rec;
+    if (!world.hit(ray, ctx, level, role, &rec)) {
+      *out = col;
+      return true;
+    }
+    if (info.distance < rec.info.distance) {
+      *out = col;
+      return true;
+    }
+    return false;
+  }
+};
+
+// ---------------------------------------------------------------- Camera (ray.rs:46-153)
+struct Camera {
+  V pos, up, sight;
+  double focus_dist, aperture, fov, aspect;
+  V right() const { return unit(cross(sight, up)); }  // :97-99
+  void look(V point) {                                // :85-89
+    sight = unit(sub(point, pos));
+    V r = right();
+    up = unit(cross(r, sight));
+  }
+  static Camera make(V from, V to) {  // :139-152 (fov default is 45 *radians*)
+    Camera c{from, v3(0., 0., 1.), v3(0., 0., 1.), 1., 0., 45., 1.};
+    c.look(to);
+    return c;
+  }
+  // One element of emit_rays (ray.rs:107-136) for pixel (w,h); the four uniforms are consumed
+  // in the reference's draw order rw, rh, theta, r.
+  Ray emit(uint64_t width, uint64_t height, uint64_t w, uint64_t h, double u_rw, double u_rh,
+           double u_theta, double u_r) const {
+    double vh = 2. * std::tan(fov / 2.) * focus_dist;
+    double vw = vh * aspect;
+    V pw = mul(right(), vw / (double)width);
+    V ph = mul(up, vh / (double)height);
+    V center = add(pos, mul(sight, focus_dist));
+    V bias = mul(sub(pw, ph), 0.5);
+    V top_left = add(add(sub(center, divs(mul(right(), vw), 2.)), divs(mul(up, vh), 2.)), bias);
+    double b = 0.5;
+    double rw = -b + (b - (-b)) * u_rw;
+    double rh = -b + (b - (-b)) * u_rh;
+    V to = sub(add(top_left, mul(pw, (double)w + rw)), mul(ph, (double)h + rh));
+    V rd = gen_point_in_disk(aperture / 2., u_theta, u_r);
+    V offset = add(mul(right(), rd.x), mul(up, rd.y));
+    V from = add(pos, offset);
+    return ray_new(from, sub(to, from));
+  }
+};
+
+static inline Ray primary_ray(const Camera& cam, uint64_t width, uint64_t height, uint64_t pid,
+                              uint32_t k0, uint32_t k1, int jitter) {
+  uint64_t npix = width * height;
+  uint64_t pix = pid % npix;
+  uint64_t w = pix % width, h = pix / width;  // image index is h*WIDTH + w (scene.rs:97)
+  PathCtx ctx{pid, k0, k1, 0};
+  U4 d = ctx.draw(LEVEL_CAMERA, PURPOSE_CAMERA);
+  if (!jitter)  // pixel centre, lens centre: used by the primary-hit fixtures
+    return cam.emit(width, height, w, h, 0.5, 0.5, 0., 0.);
+  return cam.emit(width, height, w, h, u24(d.v[0]), u24(d.v[1]), u24(d.v[2]), u24(d.v[3]));
+}
+
+}  // namespace orc
+
+// ================================================================= C API (ctypes)
+using namespace orc;
+extern "C" {
+
+struct orc_camera {  // mirrors the Camera builder (ray.rs:59-82,139)
+  double from[3], to[3];
+  double focus_dist, aperture, fov_rad, aspect;
+};
+static Camera make_camera(const orc_camera* c) {
+  Camera cam = Camera::make(v3(c->from[0], c->from[1], c->from[2]), v3(c->to[0], c->to[1], c->to[2]));
+  cam.focus_dist = c->focus_dist;
+  cam.aperture = c->aperture;
+  cam.fov = c->fov_rad;
+  cam.aspect = c->aspect;
+  return cam;
+}
+static V pv(const double* p) { return v3(p[0], p[1], p[2]); }
+
+void* orc_world_new() { return new World(); }
+void orc_world_free(void* w) { delete (World*)w; }
+
+// kind: 0 Lambertian(albedo=p0) 1 Metal(fuzz=p0, albedo=p1) 2 Dielectric(ior=p0)
+//       3 Phong(shininess=p0, diffuse=p1) 4 Specular(albedo=p0) 5 Transparent(opacity=p0, ior=p1)
+int orc_add_material(void* wp, int kind, double p0, double p1, const double* rgb) {
+  World* w = (World*)wp;
+  V c = pv(rgb);
+  Material* m = nullptr;
+  switch (kind) {
+    case 0: m = new Lambertian(p0, c); break;
+    case 1: m = new Metal(p0, p1, c); break;
+    case 2: m = new Dielectric(p0); break;
+    case 3: m = new Phong(p0, p1, c); break;
+    case 4: m = new Specular(p0); break;
+    case 5: m = new Transparent(p0, p1, c); break;
+    default: return -1;
+  }
+  w->materials.emplace_back(m);
+  return (int)w->materials.size() - 1;
+}
+static int push_obj(World* w, Shape* s, int mat, const double* mv) {
+  Object o;
+  o.shape.reset(s);
+  o.material = mat;
+  o.moving_to = pv(mv);
+  if (mv[0] != 0. || mv[1] != 0. || mv[2] != 0.) w->any_motion = true;
+  w->objects.push_back(std::move(o));
+  return (int)w->objects.size() - 1;
+}
+int orc_add_sphere(void* w, const double* c, double r, int mat, const double* mv) {
+  return push_obj((World*)w, new Sphere(pv(c), r), mat, mv);
+}
+int orc_add_triangle(void* w, const double* p0, const double* p1, const double* p2, int mat, const double* mv) {
+  return push_obj((World*)w, new Triangle(pv(p0), pv(p1), pv(p2)), mat, mv);
+}
+int orc_add_square(void* w, const double* c, const double* x, const double* y, double l, int mat, const double* mv) {
+  return push_obj((World*)w, new Square(Square::make(pv(c), pv(x), pv(y), l)), mat, mv);
+}
+int orc_add_cube(void* w, const double* c, const double* x, const double* y, double l, int mat, const double* mv) {
+  return push_obj((World*)w, new Cube(pv(c), pv(x), pv(y), l), mat, mv);
+}
+void orc_add_sky(void* w) { ((World*)w)->lights.emplace_back(new SkyLight()); }
+void orc_add_point_light(void* w, const double* pos, const double* rgb) {
+  ((World*)w)->lights.emplace_back(new PointLight(pv(pos), pv(rgb)));
+}
+void orc_add_parallel_light(void* w, const double* dir, const double* rgb) {
+  ((World*)w)->lights.emplace_back(new ParallelLight(pv(dir), pv(rgb)));
+}
+// shape_kind: 0 sphere(a=center, len=r) 1 triangle(a,b,c) 2 square(a=center,b=x,c=y,len) 3 cube(same)
+int orc_add_light_shape(void* w, int shape_kind, const double* a, const double* b, const double* c, double l) {
+  Shape* s = nullptr;
+  switch (shape_kind) {
+    case 0: s = new Sphere(pv(a), l); break;
+    case 1: s = new Triangle(pv(a), pv(b), pv(c)); break;
+    case 2: s = new Square(Square::make(pv(a), pv(b), pv(c), l)); break;
+    case 3: s = new Cube(pv(a), pv(b), pv(c), l); break;
+    default: return -1;
+  }
+  ((World*)w)->lights.emplace_back(new LightShape(s));
+  return 0;
+}
+
+// Camera basis + viewport constants (for the hand-derived vectors of SURVEY §8c (7),(8)).
+void orc_camera_basis(const orc_camera* c, double* sight, double* right, double* up, double* vh_vw_center) {
+  Camera cam = make_camera(c);
+  V r = cam.right();
+  sight[0] = cam.sight.x; sight[1] = cam.sight.y; sight[2] = cam.sight.z;
+  right[0] = r.x; right[1] = r.y; right[2] = r.z;
+  up[0] = cam.up.x; up[1] = cam.up.y; up[2] = cam.up.z;
+  double vh = 2. * std::tan(cam.fov / 2.) * cam.focus_dist;
+  V center = add(cam.pos, mul(cam.sight, cam.focus_dist));
+  vh_vw_center[0] = vh; vh_vw_center[1] = vh * cam.aspect;
+  vh_vw_center[2] = center.x; vh_vw_center[3] = center.y; vh_vw_center[4] = center.z;
+}
+
+// Primary rays for path ids [pid0, pid0+n): out = n x 6 doubles (pos, dir).
+void orc_emit_rays(const orc_camera* c, uint64_t width, uint64_t height, uint64_t pid0, uint64_t n,
+                   uint64_t seed, int jitter, double* out) {
+  Camera cam = make_camera(c);
+  for (uint64_t i = 0; i < n; ++i) {
+    Ray r = primary_ray(cam, width, height, pid0 + i, (uint32_t)seed, (uint32_t)(seed >> 32), jitter);
+    double* o = out + 6 * i;
+    o[0] = r.pos.x; o[1] = r.pos.y; o[2] = r.pos.z;
+    o[3] = r.dir.x; o[4] = r.dir.y; o[5] = r.dir.z;
+  }
+}
+
+// Closest hit (Ray::hit) for caller-supplied rays (n x 6 doubles: pos, dir taken as-is, NOT
+// re-normalised, like a struct-literal Ray).  Motion times are keyed by (seed, pid0+i, level, role).
+// out_id = object index or -1; out_t = distance; out_n = shading normal after HitInfo::new's flip;
+// out_p = hit point; out_flags bit0 = outward.
+void orc_hit(void* wp, const double* rays, uint64_t n, uint64_t seed, uint64_t pid0, uint32_t level,
+             uint32_t role, int32_t* out_id, double* out_t, double* out_n, double* out_p, int32_t* out_flags) {
+  World* w = (World*)wp;
+  for (uint64_t i = 0; i < n; ++i) {
+    const double* r = rays + 6 * i;
+    Ray ray{v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5])};
+    PathCtx ctx{pid0 + i, (uint32_t)seed, (uint32_t)(seed >> 32), 0};
+    HitRecord h;
+    if (w->hit(ray, ctx, level, role, &h)) {
+      out_id[i] = h.object;
+      out_t[i] = h.info.distance;
+      if (out_n) { out_n[3 * i] = h.info.norm.x; out_n[3 * i + 1] = h.info.norm.y; out_n[3 * i + 2] = h.info.norm.z; }
+      if (out_p) { out_p[3 * i] = h.info.hit_point.x; out_p[3 * i + 1] = h.info.hit_point.y; out_p[3 * i + 2] = h.info.hit_point.z; }
+      if (out_flags) out_flags[i] = h.info.outward ? 1 : 0;
+    } else {
+      out_id[i] = -1;
+      out_t[i] = std::numeric_limits<double>::infinity();
+      if (out_n) { out_n[3 * i] = out_n[3 * i + 1] = out_n[3 * i + 2] = 0.; }
+      if (out_p) { out_p[3 * i] = out_p[3 * i + 1] = out_p[3 * i + 2] = 0.; }
+      if (out_flags) out_flags[i] = 0;
+    }
+  }
+}
+
+// World::trace for path ids [pid0, pid0+n): out_rgb = n x 3 doubles.  Returns rays traced.
+uint64_t orc_trace_paths(void* wp, const orc_camera* c, uint64_t width, uint64_t height, uint64_t pid0,
+                         uint64_t n, uint64_t depth, uint64_t seed, int jitter, double* out_rgb) {
+  World* w = (World*)wp;
+  Camera cam = make_camera(c);
+  uint64_t rays = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    uint64_t pid = pid0 + i;
+    PathCtx ctx{pid, (uint32_t)seed, (uint32_t)(seed >> 32), 0};
+    Ray r = primary_ray(cam, width, height, pid, ctx.k0, ctx.k1, jitter);
+    V col = w->trace(r, depth, ctx, 0);
+    out_rgb[3 * i] = col.x; out_rgb[3 * i + 1] = col.y; out_rgb[3 * i + 2] = col.z;
+    rays += ctx.rays;
+  }
+  return rays;
+}
+
+// The render loop the examples hand-roll (scene.rs:82-102, cornell.rs:31-39): accum[h*W+w] += trace
+// over samples [spp_begin, spp_end); path id = sample*W*H + h*W + w.  Threads take whole rows
+// (per-thread tiles instead of the reference's global mutex).  Returns rays traced.
+uint64_t orc_render(void* wp, const orc_camera* c, uint64_t width, uint64_t height, uint64_t spp_begin,
+                    uint64_t spp_end, uint64_t depth, uint64_t seed, int nthreads, double* accum) {
+  World* w = (World*)wp;
+  Camera cam = make_camera(c);
+  uint64_t npix = width * height;
+  std::atomic<uint64_t> next_row{0};
+  std::atomic<uint64_t> total{0};
+  auto work = [&]() {
+    uint64_t rays = 0;
+    for (;;) {
+      uint64_t h = next_row.fetch_add(1);
+      if (h >= height) break;
+      for (uint64_t x = 0; x < width; ++x) {
+        V acc = v3(0., 0., 0.);
+        for (uint64_t s = spp_begin; s < spp_end; ++s) {
+          uint64_t pid = s * npix + h * width + x;
+          PathCtx ctx{pid, (uint32_t)seed, (uint32_t)(seed >> 32), 0};
+          Ray r = primary_ray(cam, width, height, pid, ctx.k0, ctx.k1, 1);
+          acc = add(acc, w->trace(r, depth, ctx, 0));
+          rays += ctx.rays;
+        }
+        double* o = accum + 3 * (h * width + x);
+        o[0] += acc.x; o[1] += acc.y; o[2] += acc.z;
+      }
+    }
+    total += rays;
+  };
+  if (nthreads <= 1) {
+    work();
+  } else {
+    std::vector<std::thread> th;
+    for (int i = 0; i < nthreads; ++i) th.emplace_back(work);
+    for (auto& t : th) t.join();
+  }
+  return total.load();
+}
+
+// scene.rs:122-127 / cornell.rs:52-57: u8 = trunc(255.99 * sqrt(clamp(c,0,1))) per channel.
+void orc_to_rgb8(const double* accum, uint64_t npix, double divisor, uint8_t* out) {
+  for (uint64_t i = 0; i < 3 * npix; ++i) {
+    double c = accum[i] / divisor;
+    double m = (1. < c) ? 1. : c;      // min!(1., c): if 1. < c {1.} else {c}
+    double x = (0. > m) ? 0. : m;      // max!(0., m): if 0. > m {0.} else {m}
+    out[i] = (uint8_t)(255.99 * std::sqrt(x));
+  }
+}
+
+// ---- small hooks so the reference's unit tests can be replayed from pytest ----
+void orc_philox(const uint32_t* ctr, const uint32_t* key, uint32_t* out) {
+  U4 r = philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
+  memcpy(out, r.v, 16);
+}
+uint32_t orc_lowbias32(uint32_t x) { return lowbias32(x); }
+// op: 0 dot(->out[0]) 1 cross 2 add 3 sub 4 mulv 5 divv 6 a*s 7 a/s 8 a+s 9 a-s 10 s-a 11 s/a 12 unit 13 len(->out[0]) 14 proj_to
+void orc_vec3_op(int op, const double* a, const double* b, double s, double* out) {
+  V x = pv(a), y = b ? pv(b) : v3(0, 0, 0), r = v3(0, 0, 0);
+  switch (op) {
+    case 0: r.x = dot(x, y); break;
+    case 1: r = cross(x, y); break;
+    case 2: r = add(x, y); break;
+    case 3: r = sub(x, y); break;
+    case 4: r = mulv(x, y); break;
+    case 5: r = v3(x.x / y.x, x.y / y.y, x.z / y.z); break;
+    case 6: r = mul(x, s); break;
+    case 7: r = divs(x, s); break;
+    case 8: r = v3(x.x + s, x.y + s, x.z + s); break;
+    case 9: r = v3(x.x - s, x.y - s, x.z - s); break;
+    case 10: r = v3(s - x.x, s - x.y, s - x.z); break;
+    case 11: r = v3(s / x.x, s / x.y, s / x.z); break;
+    case 12: r = unit(x); break;
+    case 13: r.x = len(x); break;
+    case 14: r = proj_to(x, y); break;
+  }
+  out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void orc_gen_point_in_sphere(double radius, double u0, double u1, double* out) {
+  V p = gen_point_in_sphere(radius, u0, u1);
+  out[0] = p.x; out[1] = p.y; out[2] = p.z;
+}
+void orc_gen_point_in_disk(double radius, double u0, double u1, double* out) {
+  V p = gen_point_in_disk(radius, u0, u1);
+  out[0] = p.x; out[1] = p.y; out[2] = p.z;
+}
+// Static shape hit (Shape::hit_info) with full HitInfo: out = t, n[3], p[3], dir_out[3], pos()[3], outward
+int orc_shape_hit_info(int shape_kind, const double* a, const double* b, const double* c, double l,
+                       const double* ray_pos, const double* ray_dir, int normalise, double* out) {
+  std::unique_ptr<Shape> s;
+  switch (shape_kind) {
+    case 0: s.reset(new Sphere(pv(a), l)); break;
+    case 1: s.reset(new Triangle(pv(a), pv(b), pv(c))); break;
+    case 2: s.reset(new Square(Square::make(pv(a), pv(b), pv(c), l))); break;
+    case 3: s.reset(new Cube(pv(a), pv(b), pv(c), l)); break;
+    default: return -1;
+  }
+  Ray r = normalise ? ray_new(pv(ray_pos), pv(ray_dir)) : Ray{pv(ray_pos), pv(ray_dir)};
+  HitInfo h;
+  if (!s->hit_info(r, &h)) return 0;
+  V p = hi_pos(h);
+  double v[14] = {h.distance, h.norm.x, h.norm.y, h.norm.z, h.hit_point.x, h.hit_point.y, h.hit_point.z,
+                  h.dir_out.x, h.dir_out.y, h.dir_out.z, p.x, p.y, p.z, h.outward ? 1. : 0.};
+  memcpy(out, v, sizeof v);
+  return 1;
+}
+int orc_tri_is_in_plane(const double* p0, const double* p1, const double* p2, const double* pt) {
+  return Triangle(pv(p0), pv(p1), pv(p2)).is_in_plane(pv(pt)) ? 1 : 0;
+}
+int orc_tri_contain(const double* p0, const double* p1, const double* p2, const double* pt) {
+  return Triangle(pv(p0), pv(p1), pv(p2)).contain(pv(pt)) ? 1 : 0;
+}
+// HitInfo helpers on a caller-built hit: refract / reflect_prob (ray.rs:293-316)
+int orc_hitinfo_refract(const double* n, const double* p, const double* din, double ratio, double* out_pos_dir) {
+  HitInfo h = hitinfo_new(0., pv(n), pv(p), pv(din));
+  Ray r;
+  if (!hi_refract(h, ratio, &r)) return 0;
+  out_pos_dir[0] = r.pos.x; out_pos_dir[1] = r.pos.y; out_pos_dir[2] = r.pos.z;
+  out_pos_dir[3] = r.dir.x; out_pos_dir[4] = r.dir.y; out_pos_dir[5] = r.dir.z;
+  return 1;
+}
+double orc_hitinfo_reflect_prob(const double* n, const double* din, double ior) {
+  HitInfo h = hitinfo_new(0., pv(n), v3(0, 0, 0), pv(din));
+  return hi_reflect_prob(h, ior);
+}
+void orc_sky_color(const double* dir, double* out) {
+  V c = sky_color_from(pv(dir));
+  out[0] = c.x; out[1] = c.y; out[2] = c.z;
+}
+// min!/max! (util.rs:356-380) on up to 4 values, nesting as the macro expands: f(a, f(b, f(c, d)))
+double orc_min_macro(const double* v, int n) {
+  double t = v[n - 1];
+  for (int i = n - 2; i >= 0; --i) t = (v[i] < t) ? v[i] : t;
+  return t;
+}
+double orc_max_macro(const double* v, int n) {
+  double t = v[n - 1];
+  for (int i = n - 2; i >= 0; --i) t = (v[i] > t) ? v[i] : t;
+  return t;
+}
+
+}  // extern "C"

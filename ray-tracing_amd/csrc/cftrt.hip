@@ -1,0 +1,754 @@
+// cftrt.hip — host side of libcftrt.so: the C ABI of include/cftrt.h over the kernels in kernels.h.
+// One ctx = one device + one stream.  No torch types; plain pointers and sizes.
+#include "../../include/cftrt.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_create_error = "";
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct cftrt_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  uint64_t ws_limit = 40ull << 30;
+  int variant = 0;
+  int n_cu = 256;
+  // grow-only workspace
+  DevBuf qa[2], qb[2], qc[2], h0[2], h1[2], rad, pqa, pqb, pqc, pqd, counts, accum_tmp, misc;
+  uint32_t* host_counts = nullptr;   // pinned
+  std::vector<hipEvent_t> events;
+  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+};
+
+struct cftrt_scene {
+  cftrt_ctx* ctx = nullptr;
+  bool committed = false;
+  double precise_radius = 25.0;
+  std::vector<double> sph_c, sph_r, sph_mv;
+  std::vector<int32_t> sph_obj, sph_mat;
+  std::vector<double> tri_p, tri_mv;   // 9 per tri
+  std::vector<int32_t> tri_obj, tri_mat;
+  std::vector<cftrt_material> mats;
+  std::vector<cftrt_light> lights;
+  std::vector<double> lsph, ltri;      // 4 / 9 per prim
+  std::vector<void*> dev_allocs;
+  SceneDev dev;
+};
+
+#define HIP_TRY(ctx, expr)                                                                     \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                          \
+      return CFTRT_ERR_HIP;                                                                    \
+    }                                                                                          \
+  } while (0)
+
+static int fail(cftrt_ctx* ctx, int code, const char* msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+static int ensure(cftrt_ctx* ctx, DevBuf& b, size_t bytes) {
+  if (b.bytes >= bytes && b.p) return CFTRT_OK;
+  if (b.p) {
+    HIP_TRY(ctx, hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+  }
+  if (bytes == 0) bytes = 256;
+  HIP_TRY(ctx, hipMalloc(&b.p, bytes));
+  b.bytes = bytes;
+  return CFTRT_OK;
+}
+
+template <typename T>
+static int upload(cftrt_scene* s, const std::vector<T>& v, const T** out) {
+  void* p = nullptr;
+  size_t bytes = std::max<size_t>(v.size() * sizeof(T), 256);
+  HIP_TRY(s->ctx, hipMalloc(&p, bytes));
+  s->dev_allocs.push_back(p);
+  HIP_TRY(s->ctx, hipMemsetAsync(p, 0, bytes, s->ctx->stream));
+  if (!v.empty()) HIP_TRY(s->ctx, hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s->ctx->stream));
+  *out = (const T*)p;
+  return CFTRT_OK;
+}
+
+extern "C" {
+
+int cftrt_device_count(int* out_n) {
+  if (!out_n) return CFTRT_ERR_INVALID;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    g_create_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e);
+    *out_n = 0;
+    return CFTRT_ERR_HIP;
+  }
+  *out_n = n;
+  return CFTRT_OK;
+}
+
+int cftrt_ctx_create(int device, cftrt_ctx** out) {
+  if (!out) return CFTRT_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    g_create_error = std::string("no HIP device: ") + hipGetErrorString(e);
+    return CFTRT_ERR_HIP;
+  }
+  if (device < 0 || device >= n) {
+    g_create_error = "device index out of range";
+    return CFTRT_ERR_INVALID;
+  }
+  cftrt_ctx* ctx = new cftrt_ctx();
+  ctx->device = device;
+  if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+    g_create_error = std::string("ctx_create: ") + hipGetErrorString(e);
+    delete ctx;
+    return CFTRT_ERR_HIP;
+  }
+  hipEventCreate(&ctx->ev_t0);
+  hipEventCreate(&ctx->ev_t1);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+  if ((e = hipHostMalloc((void**)&ctx->host_counts, (2 * CFTRT_MAX_LEVELS + 8) * sizeof(uint32_t))) != hipSuccess) {
+    g_create_error = std::string("hipHostMalloc: ") + hipGetErrorString(e);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return CFTRT_ERR_HIP;
+  }
+  *out = ctx;
+  return CFTRT_OK;
+}
+
+void cftrt_ctx_destroy(cftrt_ctx* ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  DevBuf* bufs[] = {&ctx->qa[0], &ctx->qa[1], &ctx->qb[0], &ctx->qb[1], &ctx->qc[0], &ctx->qc[1], &ctx->h0[0],
+                    &ctx->h0[1], &ctx->h1[0], &ctx->h1[1], &ctx->rad, &ctx->pqa, &ctx->pqb, &ctx->pqc,
+                    &ctx->pqd, &ctx->counts, &ctx->accum_tmp, &ctx->misc};
+  for (DevBuf* b : bufs)
+    if (b->p) hipFree(b->p);
+  for (hipEvent_t ev : ctx->events) hipEventDestroy(ev);
+  if (ctx->ev_t0) hipEventDestroy(ctx->ev_t0);
+  if (ctx->ev_t1) hipEventDestroy(ctx->ev_t1);
+  if (ctx->host_counts) hipHostFree(ctx->host_counts);
+  hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* cftrt_last_error(const cftrt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int cftrt_ctx_set_workspace_limit(cftrt_ctx* ctx, uint64_t bytes) {
+  if (!ctx) return CFTRT_ERR_INVALID;
+  if (bytes < (64ull << 20)) return fail(ctx, CFTRT_ERR_LIMIT, "workspace limit below 64 MiB");
+  ctx->ws_limit = bytes;
+  return CFTRT_OK;
+}
+
+int cftrt_ctx_set_variant(cftrt_ctx* ctx, int variant) {
+  if (!ctx) return CFTRT_ERR_INVALID;
+  if (variant < 0 || variant > 1) return fail(ctx, CFTRT_ERR_INVALID, "unknown intersect variant");
+  ctx->variant = variant;
+  return CFTRT_OK;
+}
+
+// ------------------------------------------------------------------ scene
+int cftrt_scene_create(cftrt_ctx* ctx, cftrt_scene** out) {
+  if (!ctx || !out) return CFTRT_ERR_INVALID;
+  cftrt_scene* s = new cftrt_scene();
+  s->ctx = ctx;
+  memset(&s->dev, 0, sizeof s->dev);
+  *out = s;
+  return CFTRT_OK;
+}
+
+void cftrt_scene_destroy(cftrt_scene* s) {
+  if (!s) return;
+  hipSetDevice(s->ctx->device);
+  hipStreamSynchronize(s->ctx->stream);
+  for (void* p : s->dev_allocs) hipFree(p);
+  delete s;
+}
+
+static int check_ids(cftrt_scene* s, const int32_t* obj, const int32_t* mat, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) {
+    if (obj[i] < 0 || mat[i] < 0) return fail(s->ctx, CFTRT_ERR_INVALID, "negative obj_id or mat_id");
+    if (i && obj[i] < obj[i - 1]) return fail(s->ctx, CFTRT_ERR_INVALID, "obj_id must be non-decreasing");
+  }
+  return CFTRT_OK;
+}
+
+int cftrt_scene_set_spheres(cftrt_scene* s, const double* center, const double* radius, const double* moving_to,
+                            const int32_t* obj_id, const int32_t* mat_id, int64_t n) {
+  if (!s) return CFTRT_ERR_INVALID;
+  if (s->committed) return fail(s->ctx, CFTRT_ERR_STATE, "scene already committed");
+  if (n < 0 || (n > 0 && (!center || !radius || !obj_id || !mat_id))) return fail(s->ctx, CFTRT_ERR_INVALID, "set_spheres: null pointer or negative n");
+  if (n > (1 << 26)) return fail(s->ctx, CFTRT_ERR_LIMIT, "set_spheres: more than 2^26 spheres");
+  if (int rc = check_ids(s, obj_id, mat_id, n)) return rc;
+  s->sph_c.assign(center, center + 3 * n);
+  s->sph_r.assign(radius, radius + n);
+  if (moving_to) s->sph_mv.assign(moving_to, moving_to + 3 * n);
+  else s->sph_mv.assign(3 * n, 0.0);
+  s->sph_obj.assign(obj_id, obj_id + n);
+  s->sph_mat.assign(mat_id, mat_id + n);
+  return CFTRT_OK;
+}
+
+int cftrt_scene_set_triangles(cftrt_scene* s, const double* p0, const double* p1, const double* p2,
+                              const double* moving_to, const int32_t* obj_id, const int32_t* mat_id, int64_t n) {
+  if (!s) return CFTRT_ERR_INVALID;
+  if (s->committed) return fail(s->ctx, CFTRT_ERR_STATE, "scene already committed");
+  if (n < 0 || (n > 0 && (!p0 || !p1 || !p2 || !obj_id || !mat_id))) return fail(s->ctx, CFTRT_ERR_INVALID, "set_triangles: null pointer or negative n");
+  if (n > (1 << 26)) return fail(s->ctx, CFTRT_ERR_LIMIT, "set_triangles: more than 2^26 triangles");
+  if (int rc = check_ids(s, obj_id, mat_id, n)) return rc;
+  s->tri_p.resize(9 * n);
+  for (int64_t i = 0; i < n; ++i) {
+    memcpy(&s->tri_p[9 * i], p0 + 3 * i, 24);
+    memcpy(&s->tri_p[9 * i + 3], p1 + 3 * i, 24);
+    memcpy(&s->tri_p[9 * i + 6], p2 + 3 * i, 24);
+  }
+  if (moving_to) s->tri_mv.assign(moving_to, moving_to + 3 * n);
+  else s->tri_mv.assign(3 * n, 0.0);
+  s->tri_obj.assign(obj_id, obj_id + n);
+  s->tri_mat.assign(mat_id, mat_id + n);
+  return CFTRT_OK;
+}
+
+int cftrt_scene_set_materials(cftrt_scene* s, const cftrt_material* table, int64_t n) {
+  if (!s) return CFTRT_ERR_INVALID;
+  if (s->committed) return fail(s->ctx, CFTRT_ERR_STATE, "scene already committed");
+  if (n < 0 || (n > 0 && !table)) return fail(s->ctx, CFTRT_ERR_INVALID, "set_materials: null pointer or negative n");
+  for (int64_t i = 0; i < n; ++i)
+    if (table[i].kind < 0 || table[i].kind > 5) return fail(s->ctx, CFTRT_ERR_INVALID, "set_materials: unknown kind");
+  s->mats.assign(table, table + n);
+  return CFTRT_OK;
+}
+
+int cftrt_scene_set_lights(cftrt_scene* s, const cftrt_light* lights, int64_t n_lights, const double* lsph_center,
+                           const double* lsph_radius, int64_t n_lsph, const double* ltri_p0, const double* ltri_p1,
+                           const double* ltri_p2, int64_t n_ltri) {
+  if (!s) return CFTRT_ERR_INVALID;
+  if (s->committed) return fail(s->ctx, CFTRT_ERR_STATE, "scene already committed");
+  if (n_lights < 0 || n_lsph < 0 || n_ltri < 0 || (n_lights > 0 && !lights) ||
+      (n_lsph > 0 && (!lsph_center || !lsph_radius)) || (n_ltri > 0 && (!ltri_p0 || !ltri_p1 || !ltri_p2)))
+    return fail(s->ctx, CFTRT_ERR_INVALID, "set_lights: null pointer or negative n");
+  if (n_lights > 64) return fail(s->ctx, CFTRT_ERR_LIMIT, "set_lights: more than 64 lights");
+  for (int64_t i = 0; i < n_lights; ++i) {
+    const cftrt_light& L = lights[i];
+    if (L.kind < 0 || L.kind > 3) return fail(s->ctx, CFTRT_ERR_INVALID, "set_lights: unknown kind");
+    if (L.kind == CFTRT_LIGHT_SHAPE) {
+      if (L.sph_begin < 0 || L.sph_count < 0 || L.sph_begin + (int64_t)L.sph_count > n_lsph || L.tri_begin < 0 ||
+          L.tri_count < 0 || L.tri_begin + (int64_t)L.tri_count > n_ltri)
+        return fail(s->ctx, CFTRT_ERR_INVALID, "set_lights: shape range out of bounds");
+    }
+  }
+  s->lights.assign(lights, lights + n_lights);
+  s->lsph.resize(4 * n_lsph);
+  for (int64_t i = 0; i < n_lsph; ++i) {
+    memcpy(&s->lsph[4 * i], lsph_center + 3 * i, 24);
+    s->lsph[4 * i + 3] = lsph_radius[i];
+  }
+  s->ltri.resize(9 * n_ltri);
+  for (int64_t i = 0; i < n_ltri; ++i) {
+    memcpy(&s->ltri[9 * i], ltri_p0 + 3 * i, 24);
+    memcpy(&s->ltri[9 * i + 3], ltri_p1 + 3 * i, 24);
+    memcpy(&s->ltri[9 * i + 6], ltri_p2 + 3 * i, 24);
+  }
+  return CFTRT_OK;
+}
+
+int cftrt_scene_set_precise_radius(cftrt_scene* s, double radius) {
+  if (!s) return CFTRT_ERR_INVALID;
+  if (s->committed) return fail(s->ctx, CFTRT_ERR_STATE, "scene already committed");
+  if (!(radius > 0.0)) return fail(s->ctx, CFTRT_ERR_INVALID, "precise radius must be positive");
+  s->precise_radius = radius;
+  return CFTRT_OK;
+}
+
+int cftrt_scene_commit(cftrt_scene* s) {
+  if (!s) return CFTRT_ERR_INVALID;
+  if (s->committed) return fail(s->ctx, CFTRT_ERR_STATE, "scene already committed");
+  cftrt_ctx* ctx = s->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int ns = (int)s->sph_r.size(), nt = (int)s->tri_obj.size();
+  const int nm = (int)s->mats.size();
+  for (int i = 0; i < ns; ++i)
+    if (s->sph_mat[i] >= nm) return fail(ctx, CFTRT_ERR_INVALID, "sphere mat_id beyond the material table");
+  for (int i = 0; i < nt; ++i)
+    if (s->tri_mat[i] >= nm) return fail(ctx, CFTRT_ERR_INVALID, "triangle mat_id beyond the material table");
+
+  std::vector<float4> sphF, msphF, msphMv, triF, mtriF;
+  std::vector<int> sphF_gid, msph_gid, prec_gid, triF_gid, mtri_gid, prim_obj(ns + nt), prim_mat(ns + nt);
+  std::vector<double> sphD(4 * (size_t)ns);
+  int any_motion = 0;
+  for (int i = 0; i < ns; ++i) {
+    const double* c = &s->sph_c[3 * i];
+    const double* mv = &s->sph_mv[3 * i];
+    double r = s->sph_r[i];
+    sphD[4 * i] = c[0]; sphD[4 * i + 1] = c[1]; sphD[4 * i + 2] = c[2]; sphD[4 * i + 3] = r;
+    prim_obj[i] = s->sph_obj[i];
+    prim_mat[i] = s->sph_mat[i];
+    bool moving = mv[0] != 0. || mv[1] != 0. || mv[2] != 0.;
+    if (moving) any_motion = 1;
+    if (std::fabs(r) >= s->precise_radius) {
+      prec_gid.push_back(i);
+    } else if (moving) {
+      msphF.push_back(make_float4((float)c[0], (float)c[1], (float)c[2], (float)(r * r)));
+      msphMv.push_back(make_float4((float)mv[0], (float)mv[1], (float)mv[2], 0.f));
+      msph_gid.push_back(i);
+    } else {
+      sphF.push_back(make_float4((float)c[0], (float)c[1], (float)c[2], (float)(r * r)));
+      sphF_gid.push_back(i);
+    }
+  }
+  for (int i = 0; i < nt; ++i) {
+    const double* p = &s->tri_p[9 * i];
+    const double* mv = &s->tri_mv[3 * i];
+    prim_obj[ns + i] = s->tri_obj[i];
+    prim_mat[ns + i] = s->tri_mat[i];
+    bool moving = mv[0] != 0. || mv[1] != 0. || mv[2] != 0.;
+    float4 P0 = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f);
+    float4 E1 = make_float4((float)(p[3] - p[0]), (float)(p[4] - p[1]), (float)(p[5] - p[2]), 0.f);
+    float4 E2 = make_float4((float)(p[6] - p[0]), (float)(p[7] - p[1]), (float)(p[8] - p[2]), 0.f);
+    if (moving) {
+      any_motion = 1;
+      mtriF.push_back(P0); mtriF.push_back(E1); mtriF.push_back(E2);
+      mtriF.push_back(make_float4((float)mv[0], (float)mv[1], (float)mv[2], 0.f));
+      mtri_gid.push_back(ns + i);
+    } else {
+      triF.push_back(P0); triF.push_back(E1); triF.push_back(E2);
+      triF_gid.push_back(ns + i);
+    }
+  }
+  std::vector<MatDev> mats(nm);
+  int n_phong = 0;
+  for (int i = 0; i < nm; ++i) {
+    const cftrt_material& m = s->mats[i];
+    mats[i] = MatDev{m.kind, (float)m.p0, (float)m.p1, (float)m.color[0], (float)m.color[1], (float)m.color[2], 0.f, 0.f};
+    if (m.kind == CFTRT_MAT_PHONG) n_phong++;
+  }
+  std::vector<LightDev> lights(s->lights.size());
+  for (size_t i = 0; i < s->lights.size(); ++i) {
+    const cftrt_light& L = s->lights[i];
+    lights[i] = LightDev{L.kind, L.sph_begin, L.sph_count, L.tri_begin, L.tri_count, (float)L.v[0], (float)L.v[1],
+                         (float)L.v[2], (float)L.color[0], (float)L.color[1], (float)L.color[2]};
+    if (L.kind == CFTRT_LIGHT_SHAPE) { lights[i].r = lights[i].g = lights[i].b = 1.0f; }   // light.rs:198-204
+  }
+  SceneDev& D = s->dev;
+  memset(&D, 0, sizeof D);
+  int rc;
+  if ((rc = upload(s, sphF, &D.sphF))) return rc;
+  if ((rc = upload(s, sphF_gid, &D.sphF_gid))) return rc;
+  if ((rc = upload(s, msphF, &D.msphF))) return rc;
+  if ((rc = upload(s, msphMv, &D.msphMv))) return rc;
+  if ((rc = upload(s, msph_gid, &D.msph_gid))) return rc;
+  if ((rc = upload(s, prec_gid, &D.prec_gid))) return rc;
+  if ((rc = upload(s, triF, &D.triF))) return rc;
+  if ((rc = upload(s, triF_gid, &D.triF_gid))) return rc;
+  if ((rc = upload(s, mtriF, &D.mtriF))) return rc;
+  if ((rc = upload(s, mtri_gid, &D.mtri_gid))) return rc;
+  if ((rc = upload(s, sphD, &D.sphD))) return rc;
+  if ((rc = upload(s, s->sph_mv, &D.sphMvD))) return rc;
+  if ((rc = upload(s, s->tri_p, &D.triD))) return rc;
+  if ((rc = upload(s, s->tri_mv, &D.triMvD))) return rc;
+  if ((rc = upload(s, prim_obj, &D.prim_obj))) return rc;
+  if ((rc = upload(s, prim_mat, &D.prim_mat))) return rc;
+  if ((rc = upload(s, mats, &D.mats))) return rc;
+  if ((rc = upload(s, lights, &D.lights))) return rc;
+  if ((rc = upload(s, s->lsph, &D.lsphD))) return rc;
+  if ((rc = upload(s, s->ltri, &D.ltriD))) return rc;
+  D.n_sphF = (int)sphF_gid.size();
+  D.n_msph = (int)msph_gid.size();
+  D.n_prec = (int)prec_gid.size();
+  D.n_triF = (int)triF_gid.size();
+  D.n_mtri = (int)mtri_gid.size();
+  D.n_sph = ns;
+  D.n_tri = nt;
+  D.n_mat = nm;
+  D.n_lights = (int)lights.size();
+  D.any_motion = any_motion;
+  D.n_phong_mats = n_phong;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  s->committed = true;
+  return CFTRT_OK;
+}
+
+// ------------------------------------------------------------------ camera
+static void v_unit(double* v) {
+  double l = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  v[0] /= l; v[1] /= l; v[2] /= l;
+}
+// Viewport constants of Camera::emit_rays (ray.rs:112-118), in f64.
+static int make_cam(cftrt_ctx* ctx, const cftrt_camera* c, uint32_t width, uint32_t height, CamDev* out) {
+  if (!c) return fail(ctx, CFTRT_ERR_INVALID, "null camera");
+  if (width == 0 || height == 0) return fail(ctx, CFTRT_ERR_INVALID, "zero image size");
+  const double* s = c->sight;
+  const double* u = c->up;
+  double right[3] = {s[1] * u[2] - s[2] * u[1], s[2] * u[0] - s[0] * u[2], s[0] * u[1] - s[1] * u[0]};
+  v_unit(right);
+  double vh = 2. * std::tan(c->fov_rad / 2.) * c->focus_dist;
+  double vw = vh * c->aspect;
+  double pw[3], ph[3], tl[3];
+  for (int k = 0; k < 3; ++k) {
+    pw[k] = vw / (double)width * right[k];
+    ph[k] = vh / (double)height * u[k];
+  }
+  for (int k = 0; k < 3; ++k) {
+    double center = c->pos[k] + c->focus_dist * s[k];
+    double bias = 0.5 * (pw[k] - ph[k]);
+    tl[k] = center - vw * right[k] / 2. + vh * u[k] / 2. + bias;
+  }
+  CamDev C;
+  C.tlx = (float)tl[0]; C.tly = (float)tl[1]; C.tlz = (float)tl[2];
+  C.pwx = (float)pw[0]; C.pwy = (float)pw[1]; C.pwz = (float)pw[2];
+  C.phx = (float)ph[0]; C.phy = (float)ph[1]; C.phz = (float)ph[2];
+  C.px = (float)c->pos[0]; C.py = (float)c->pos[1]; C.pz = (float)c->pos[2];
+  C.rx = (float)right[0]; C.ry = (float)right[1]; C.rz = (float)right[2];
+  C.ux = (float)u[0]; C.uy = (float)u[1]; C.uz = (float)u[2];
+  C.lens_radius = (float)(c->aperture / 2.);
+  C.width = width;
+  C.height = height;
+  *out = C;
+  return CFTRT_OK;
+}
+
+// ------------------------------------------------------------------ the trace loop
+static uint32_t grid_for(cftrt_ctx* ctx, uint64_t n, uint32_t per_cu) {
+  uint64_t blocks = (n + CFT_BLOCK - 1) / CFT_BLOCK;
+  uint64_t cap = (uint64_t)ctx->n_cu * per_cu;
+  if (blocks > cap) blocks = cap;
+  if (blocks == 0) blocks = 1;
+  return (uint32_t)blocks;
+}
+
+struct EvTimer {   // pairs of events around launches on the ctx stream, summed per class after a sync
+  cftrt_ctx* ctx;
+  size_t used = 0;
+  std::vector<std::pair<size_t, int>> spans;   // (start event index, class)
+  int begin(int cls) {
+    if (used + 2 > ctx->events.size()) {
+      size_t old = ctx->events.size();
+      ctx->events.resize(old + 256);
+      for (size_t i = old; i < ctx->events.size(); ++i)
+        if (hipEventCreate(&ctx->events[i]) != hipSuccess) return -1;
+    }
+    spans.push_back({used, cls});
+    hipEventRecord(ctx->events[used], ctx->stream);
+    used += 2;
+    return 0;
+  }
+  void end() { hipEventRecord(ctx->events[spans.back().first + 1], ctx->stream); }
+  void collect(double* ms_by_class, uint32_t* n_by_class) {
+    for (auto& sp : spans) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ctx->events[sp.first], ctx->events[sp.first + 1]) == hipSuccess) {
+        ms_by_class[sp.second] += ms;
+        n_by_class[sp.second] += 1;
+      }
+    }
+    spans.clear();
+    used = 0;
+  }
+};
+enum { CLS_GEN = 0, CLS_ISECT, CLS_SHADE, CLS_SHADOW, CLS_RESOLVE, CLS_N };
+
+// Renders path ids [pid_base, pid_base + P) (P = npix * nsamples) into the radiance buffer and, when
+// accum_dev != null, resolves them into accum_dev.
+static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t P, uint32_t nsamples, uint32_t npix,
+                    uint32_t max_depth, uint64_t seed, int jitter, float* accum_dev, cftrt_stats* st, EvTimer& tm) {
+  cftrt_ctx* ctx = s->ctx;
+  const SceneDev& S = s->dev;
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  const bool phong = S.n_phong_mats > 0;
+  const bool two_scans = S.any_motion && S.n_lights > 0;   // `looked` and trace each draw their own motion times
+  int rc;
+  for (int k = 0; k < 2; ++k) {
+    if ((rc = ensure(ctx, ctx->qa[k], (size_t)P * 16))) return rc;
+    if ((rc = ensure(ctx, ctx->qb[k], (size_t)P * 16))) return rc;
+    if ((rc = ensure(ctx, ctx->qc[k], (size_t)P * 8))) return rc;
+  }
+  for (int k = 0; k < (two_scans ? 2 : 1); ++k) {
+    if ((rc = ensure(ctx, ctx->h0[k], (size_t)P * 16))) return rc;
+    if ((rc = ensure(ctx, ctx->h1[k], (size_t)P * 16))) return rc;
+  }
+  if ((rc = ensure(ctx, ctx->rad, (size_t)P * 16))) return rc;
+  if (phong) {
+    if ((rc = ensure(ctx, ctx->pqa, (size_t)P * 16))) return rc;
+    if ((rc = ensure(ctx, ctx->pqb, (size_t)P * 16))) return rc;
+    if ((rc = ensure(ctx, ctx->pqc, (size_t)P * 16))) return rc;
+    if ((rc = ensure(ctx, ctx->pqd, (size_t)P * 8))) return rc;
+  }
+  const size_t ncount = 2 * CFTRT_MAX_LEVELS + 8;   // [0..L] level counts, [L+1..2L] phong counts, then misc
+  if ((rc = ensure(ctx, ctx->counts, ncount * 4))) return rc;
+  uint32_t* counts = (uint32_t*)ctx->counts.p;
+  uint32_t* phong_counts = counts + CFTRT_MAX_LEVELS + 1;
+  uint32_t* rescans = counts + 2 * CFTRT_MAX_LEVELS + 2;
+  hipStream_t st_ = ctx->stream;
+  HIP_TRY(ctx, hipMemsetAsync(counts, 0, ncount * 4, st_));
+  HIP_TRY(ctx, hipMemcpyAsync(counts, &P, 4, hipMemcpyHostToDevice, st_));
+
+  QueueDev q[2];
+  for (int k = 0; k < 2; ++k) q[k] = QueueDev{(float4*)ctx->qa[k].p, (float4*)ctx->qb[k].p, (float2*)ctx->qc[k].p};
+  HitDev hA{(float4*)ctx->h0[0].p, (float4*)ctx->h1[0].p};
+  HitDev hB = two_scans ? HitDev{(float4*)ctx->h0[1].p, (float4*)ctx->h1[1].p} : hA;
+  PhongQueueDev pq{(float4*)ctx->pqa.p, (float4*)ctx->pqb.p, (float4*)ctx->pqc.p, (uint2*)ctx->pqd.p};
+  float4* rad = (float4*)ctx->rad.p;
+
+  if (tm.begin(CLS_GEN)) return fail(ctx, CFTRT_ERR_HIP, "hipEventCreate failed");
+  hipLaunchKernelGGL(k_generate, dim3(grid_for(ctx, P, 16)), dim3(CFT_BLOCK), 0, st_, C, pid_base, P, k0, k1, jitter, q[0]);
+  tm.end();
+
+  const uint32_t grid = grid_for(ctx, P, 8);
+  uint32_t levels_run = 0;
+  for (uint32_t level = 0; level < max_depth; ++level) {
+    int in = level & 1, outq = in ^ 1;
+    const uint32_t nl = (uint32_t)S.n_lights;
+    tm.begin(CLS_ISECT);
+    if (two_scans)
+      hipLaunchKernelGGL(k_intersect, dim3(grid), dim3(CFT_BLOCK), 0, st_, S, q[in], counts, level, pid_base, k0, k1,
+                         0u, hA, rescans);
+    hipLaunchKernelGGL(k_intersect, dim3(grid), dim3(CFT_BLOCK), 0, st_, S, q[in], counts, level, pid_base, k0, k1, nl,
+                       hB, rescans);
+    tm.end();
+    tm.begin(CLS_SHADE);
+    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(CFT_BLOCK), 0, st_, S, q[in], hA, hB, counts, level, max_depth, pid_base,
+                       k0, k1, q[outq], rad, pq, phong_counts);
+    tm.end();
+    if (phong) {
+      tm.begin(CLS_SHADOW);
+      hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(CFT_BLOCK), 0, st_, S, pq, phong_counts, level, pid_base, k0, k1, rad,
+                         rescans);
+      tm.end();
+    }
+    levels_run = level + 1;
+    // every 4 levels look at the next level's count; stop when the queue has drained
+    if ((level & 3) == 3 && level + 1 < max_depth) {
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->host_counts, counts + level + 1, 4, hipMemcpyDeviceToHost, st_));
+      HIP_TRY(ctx, hipStreamSynchronize(st_));
+      if (ctx->host_counts[0] == 0) break;
+    }
+  }
+  if (accum_dev) {
+    tm.begin(CLS_RESOLVE);
+    hipLaunchKernelGGL(k_resolve, dim3(grid_for(ctx, npix, 16)), dim3(CFT_BLOCK), 0, st_, rad, npix, nsamples, accum_dev);
+    tm.end();
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->host_counts, counts, ncount * 4, hipMemcpyDeviceToHost, st_));
+  HIP_TRY(ctx, hipStreamSynchronize(st_));
+  HIP_TRY(ctx, hipGetLastError());
+  if (st) {
+    const uint32_t* hc = ctx->host_counts;
+    const uint32_t* hp = hc + CFTRT_MAX_LEVELS + 1;
+    for (uint32_t l = 0; l < levels_run && l < CFTRT_MAX_LEVELS; ++l) {
+      st->rays_per_level[l] += hc[l];
+      st->rays += hc[l];
+      uint64_t pr = (uint64_t)hp[l] * (uint64_t)S.n_lights;
+      st->phong_rays += pr;
+      st->rays += pr;
+      if (hc[l] && l + 1 > st->levels) st->levels = l + 1;
+    }
+    st->exact_rescan += hc[2 * CFTRT_MAX_LEVELS + 2];
+    st->paths += P;
+    st->passes += 1;
+  }
+  return CFTRT_OK;
+}
+
+static int render_impl(cftrt_scene* s, const cftrt_camera* cam, uint32_t width, uint32_t height, uint32_t spp_begin,
+                       uint32_t spp_end, uint32_t max_depth, uint64_t seed, float* accum_dev, cftrt_stats* stats) {
+  cftrt_ctx* ctx = s->ctx;
+  if (!s->committed) return fail(ctx, CFTRT_ERR_STATE, "scene not committed");
+  if (spp_end < spp_begin) return fail(ctx, CFTRT_ERR_INVALID, "spp_end < spp_begin");
+  if (max_depth > CFTRT_MAX_LEVELS) return fail(ctx, CFTRT_ERR_LIMIT, "max_depth beyond CFTRT_MAX_LEVELS (256)");
+  CamDev C;
+  if (int rc = make_cam(ctx, cam, width, height, &C)) return rc;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const uint64_t npix = (uint64_t)width * height;
+  if (npix > (1ull << 31)) return fail(ctx, CFTRT_ERR_LIMIT, "image beyond 2^31 pixels");
+  const bool two_scans = s->dev.any_motion && s->dev.n_lights > 0;
+  const uint64_t bytes_per_path = 80 + 16 + (two_scans ? 64 : 32) + (s->dev.n_phong_mats ? 56 : 0);
+  uint64_t spp_pass = ctx->ws_limit / (bytes_per_path * npix);
+  spp_pass = std::min<uint64_t>(spp_pass, 0xFFFFFF00ull / npix);
+  if (spp_pass == 0) return fail(ctx, CFTRT_ERR_LIMIT, "one sample per pixel does not fit the workspace limit");
+  cftrt_stats st;
+  memset(&st, 0, sizeof st);
+  EvTimer tm{ctx};
+  double ms[CLS_N] = {0};
+  uint32_t nl[CLS_N] = {0};
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
+  for (uint32_t sb = spp_begin; sb < spp_end;) {
+    uint32_t ns = (uint32_t)std::min<uint64_t>(spp_pass, spp_end - sb);
+    uint64_t pid_base = (uint64_t)sb * npix;
+    int rc = run_pass(s, C, pid_base, (uint32_t)(npix * ns), ns, (uint32_t)npix, max_depth, seed, 1, accum_dev, &st, tm);
+    if (rc) return rc;
+    sb += ns;
+    tm.collect(ms, nl);   // run_pass has synchronised: fold this pass's kernel spans
+  }
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  float msT = 0.f;
+  hipEventElapsedTime(&msT, ctx->ev_t0, ctx->ev_t1);
+  st.ms_total = msT;
+  st.ms_generate = ms[CLS_GEN];
+  st.ms_intersect = ms[CLS_ISECT];
+  st.ms_shade = ms[CLS_SHADE];
+  st.ms_shadow = ms[CLS_SHADOW];
+  st.ms_resolve = ms[CLS_RESOLVE];
+  st.launches_intersect = nl[CLS_ISECT];
+  const double per_ray_scan = 16.0 * s->dev.n_sph + 44.0 * s->dev.n_tri;
+  st.flops_intersect = (double)st.rays * per_ray_scan;
+  st.flops = (double)st.rays * (per_ray_scan + 200.0);
+  if (stats) *stats = st;
+  return CFTRT_OK;
+}
+
+int cftrt_render_device(cftrt_scene* s, const cftrt_camera* cam, uint32_t width, uint32_t height, uint32_t spp_begin,
+                        uint32_t spp_end, uint32_t max_depth, uint64_t seed, void* accum_device, cftrt_stats* stats) {
+  if (!s) return CFTRT_ERR_INVALID;
+  if (!accum_device) return fail(s->ctx, CFTRT_ERR_INVALID, "null accumulation buffer");
+  return render_impl(s, cam, width, height, spp_begin, spp_end, max_depth, seed, (float*)accum_device, stats);
+}
+
+int cftrt_render(cftrt_scene* s, const cftrt_camera* cam, uint32_t width, uint32_t height, uint32_t spp_begin,
+                 uint32_t spp_end, uint32_t max_depth, uint64_t seed, float* accum_host, cftrt_stats* stats) {
+  if (!s) return CFTRT_ERR_INVALID;
+  cftrt_ctx* ctx = s->ctx;
+  if (!accum_host) return fail(ctx, CFTRT_ERR_INVALID, "null accumulation buffer");
+  if (width == 0 || height == 0) return fail(ctx, CFTRT_ERR_INVALID, "zero image size");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  size_t bytes = (size_t)width * height * 3 * sizeof(float);
+  if (int rc = ensure(ctx, ctx->accum_tmp, bytes)) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->accum_tmp.p, accum_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  int rc = render_impl(s, cam, width, height, spp_begin, spp_end, max_depth, seed, (float*)ctx->accum_tmp.p, stats);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(accum_host, ctx->accum_tmp.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return CFTRT_OK;
+}
+
+// ------------------------------------------------------------------ parity hooks
+int cftrt_generate(cftrt_ctx* ctx, const cftrt_camera* cam, uint32_t width, uint32_t height, uint64_t pid0, uint64_t n,
+                   uint64_t seed, int jitter, float* out_rays) {
+  if (!ctx) return CFTRT_ERR_INVALID;
+  if (!out_rays && n) return fail(ctx, CFTRT_ERR_INVALID, "null output");
+  if (n > (1ull << 28)) return fail(ctx, CFTRT_ERR_LIMIT, "generate hook: more than 2^28 rays");
+  CamDev C;
+  if (int rc = make_cam(ctx, cam, width, height, &C)) return rc;
+  if (n == 0) return CFTRT_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure(ctx, ctx->qa[0], n * 16)) || (rc = ensure(ctx, ctx->qb[0], n * 16)) || (rc = ensure(ctx, ctx->qc[0], n * 8))) return rc;
+  QueueDev q{(float4*)ctx->qa[0].p, (float4*)ctx->qb[0].p, (float2*)ctx->qc[0].p};
+  hipLaunchKernelGGL(k_generate, dim3(grid_for(ctx, n, 16)), dim3(CFT_BLOCK), 0, ctx->stream, C, pid0, (uint32_t)n,
+                     (uint32_t)seed, (uint32_t)(seed >> 32), jitter, q);
+  std::vector<float4> a(n), b(n);
+  HIP_TRY(ctx, hipMemcpyAsync(a.data(), q.a, n * 16, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(b.data(), q.b, n * 16, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipGetLastError());
+  for (uint64_t i = 0; i < n; ++i) {
+    float* o = out_rays + 6 * i;
+    o[0] = a[i].x; o[1] = a[i].y; o[2] = a[i].z; o[3] = a[i].w; o[4] = b[i].x; o[5] = b[i].y;
+  }
+  return CFTRT_OK;
+}
+
+int cftrt_intersect(cftrt_scene* s, const float* rays, uint64_t n, uint64_t seed, uint64_t pid0, uint32_t level,
+                    uint32_t role, int32_t* out_id, double* out_t, float* out_normal, float* out_point) {
+  if (!s) return CFTRT_ERR_INVALID;
+  cftrt_ctx* ctx = s->ctx;
+  if (!s->committed) return fail(ctx, CFTRT_ERR_STATE, "scene not committed");
+  if (n && (!rays || !out_id)) return fail(ctx, CFTRT_ERR_INVALID, "null rays or out_id");
+  if (n > (1ull << 28)) return fail(ctx, CFTRT_ERR_LIMIT, "intersect hook: more than 2^28 rays");
+  if (n == 0) return CFTRT_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // layout in misc: rays (24n) | id (4n) | t (8n) | n (12n) | p (12n) | counter
+  size_t off_id = 24 * n, off_t = off_id + 4 * n;
+  off_t = (off_t + 7) & ~(size_t)7;
+  size_t off_n = off_t + 8 * n, off_p = off_n + 12 * n, off_c = off_p + 12 * n, total = off_c + 16;
+  if (int rc = ensure(ctx, ctx->misc, total)) return rc;
+  char* base = (char*)ctx->misc.p;
+  HIP_TRY(ctx, hipMemcpyAsync(base, rays, 24 * n, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(base + off_c, 0, 16, ctx->stream));
+  hipLaunchKernelGGL(k_intersect_hook, dim3(grid_for(ctx, n, 8)), dim3(CFT_BLOCK), 0, ctx->stream, s->dev,
+                     (const float*)base, (uint32_t)n, pid0, level, role, (uint32_t)seed, (uint32_t)(seed >> 32),
+                     (int32_t*)(base + off_id), (double*)(base + off_t), (float*)(base + off_n), (float*)(base + off_p),
+                     (uint32_t*)(base + off_c));
+  HIP_TRY(ctx, hipMemcpyAsync(out_id, base + off_id, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
+  if (out_t) HIP_TRY(ctx, hipMemcpyAsync(out_t, base + off_t, 8 * n, hipMemcpyDeviceToHost, ctx->stream));
+  if (out_normal) HIP_TRY(ctx, hipMemcpyAsync(out_normal, base + off_n, 12 * n, hipMemcpyDeviceToHost, ctx->stream));
+  if (out_point) HIP_TRY(ctx, hipMemcpyAsync(out_point, base + off_p, 12 * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipGetLastError());
+  return CFTRT_OK;
+}
+
+int cftrt_trace_paths(cftrt_scene* s, const cftrt_camera* cam, uint32_t width, uint32_t height, uint64_t pid0, uint64_t n,
+                      uint32_t max_depth, uint64_t seed, int jitter, float* out_rgb, cftrt_stats* stats) {
+  if (!s) return CFTRT_ERR_INVALID;
+  cftrt_ctx* ctx = s->ctx;
+  if (!s->committed) return fail(ctx, CFTRT_ERR_STATE, "scene not committed");
+  if (n && !out_rgb) return fail(ctx, CFTRT_ERR_INVALID, "null output");
+  if (n > (1ull << 26)) return fail(ctx, CFTRT_ERR_LIMIT, "trace_paths hook: more than 2^26 paths");
+  if (max_depth > CFTRT_MAX_LEVELS) return fail(ctx, CFTRT_ERR_LIMIT, "max_depth beyond CFTRT_MAX_LEVELS (256)");
+  CamDev C;
+  if (int rc = make_cam(ctx, cam, width, height, &C)) return rc;
+  cftrt_stats st;
+  memset(&st, 0, sizeof st);
+  if (n == 0) { if (stats) *stats = st; return CFTRT_OK; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  EvTimer tm{ctx};
+  if (max_depth == 0) {
+    memset(out_rgb, 0, 12 * n);
+    if (stats) *stats = st;
+    return CFTRT_OK;
+  }
+  int rc = run_pass(s, C, pid0, (uint32_t)n, 1, (uint32_t)n, max_depth, seed, jitter, nullptr, &st, tm);
+  if (rc) return rc;
+  std::vector<float4> rad(n);
+  HIP_TRY(ctx, hipMemcpy(rad.data(), ctx->rad.p, n * 16, hipMemcpyDeviceToHost));
+  for (uint64_t i = 0; i < n; ++i) {
+    out_rgb[3 * i] = rad[i].x; out_rgb[3 * i + 1] = rad[i].y; out_rgb[3 * i + 2] = rad[i].z;
+  }
+  const double per_ray_scan = 16.0 * s->dev.n_sph + 44.0 * s->dev.n_tri;
+  st.flops_intersect = (double)st.rays * per_ray_scan;
+  st.flops = (double)st.rays * (per_ray_scan + 200.0);
+  if (stats) *stats = st;
+  return CFTRT_OK;
+}
+
+int cftrt_resolve_rgb8(cftrt_ctx* ctx, const float* accum_host, uint64_t npix, double divisor, uint8_t* out_rgb8) {
+  if (!ctx) return CFTRT_ERR_INVALID;
+  if (npix && (!accum_host || !out_rgb8)) return fail(ctx, CFTRT_ERR_INVALID, "null buffer");
+  if (!(divisor > 0.0)) return fail(ctx, CFTRT_ERR_INVALID, "divisor must be positive");
+  if (npix > (1ull << 31)) return fail(ctx, CFTRT_ERR_LIMIT, "image beyond 2^31 pixels");
+  if (npix == 0) return CFTRT_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  size_t nf = 3 * npix;
+  if (int rc = ensure(ctx, ctx->misc, nf * 4 + nf)) return rc;
+  char* base = (char*)ctx->misc.p;
+  HIP_TRY(ctx, hipMemcpyAsync(base, accum_host, nf * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_rgb8, dim3(grid_for(ctx, nf, 16)), dim3(CFT_BLOCK), 0, ctx->stream, (const float*)base,
+                     (uint64_t)nf, (float)divisor, (uint8_t*)(base + nf * 4));
+  HIP_TRY(ctx, hipMemcpyAsync(out_rgb8, base + nf * 4, nf, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipGetLastError());
+  return CFTRT_OK;
+}
+
+}  // extern "C"

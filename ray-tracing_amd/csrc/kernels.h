@@ -1,0 +1,680 @@
+// kernels.h — the wavefront trace loop for gfx950: generate / intersect / shade / shadow / resolve.
+//
+// What each kernel replaces in the reference (cfeitong/ray-tracing):
+//   k_generate  Camera::emit_rays                      src/ray.rs:107-136
+//   k_intersect Ray::hit + Object::hit_by + Shape::hit src/ray.rs:18-28, src/object.rs:42-55,99-138,272-302
+//   k_shade     World::trace body, HitInfo::new, Material::{scatter,render}, LightSource::looked
+//                                                      src/object.rs:326-355, src/ray.rs:233-316,
+//                                                      src/material/*.rs, src/light.rs:184-190,233-242
+//   k_shadow    PhongModel::render + is_in_shadow      src/material/basic.rs:56-98, src/light.rs
+//   k_resolve   raw[h*W+w] += p                        examples/scene.rs:97
+//
+// Numerics.  The linear scan culls in f32 (cancellation-free discriminant, r^2 - |oc - (oc.d)d|^2)
+// and the surviving candidate is re-evaluated in f64 with the reference's own formula, operation
+// for operation, so the reported hit distance is the f64 value the reference computes for the
+// same ray.  Built with -ffp-contract=off: every FMA in this file is explicit.
+#pragma once
+#include "device_math.h"
+#include "scene_dev.h"
+
+#define CFT_BLOCK 256
+
+// constant-address-space views: a wave-uniform index then compiles to s_load (SGPR operands)
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const v4f __attribute__((address_space(4))) * c_f4p;
+typedef const int __attribute__((address_space(4))) * c_i32p;
+typedef const double __attribute__((address_space(4))) * c_f64p;
+#define AS_CONST(T, p) ((T)(uintptr_t)(p))
+
+// ------------------------------------------------------------------ f64 exact evaluation
+struct d3 {
+  double x, y, z;
+};
+__device__ __forceinline__ d3 operator+(d3 a, d3 b) { return d3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ d3 operator-(d3 a, d3 b) { return d3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ d3 operator*(d3 a, double s) { return d3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ double ddot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ double dlen2(d3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+__device__ __forceinline__ d3 dcross(d3 a, d3 b) {
+  return d3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ d3 dunit(d3 a) {
+  double l = sqrt(dlen2(a));
+  return d3{a.x / l, a.y / l, a.z / l};
+}
+
+// Sphere::hit_info, object.rs:273-286, same operation order.
+__device__ __forceinline__ bool exact_sphere(d3 o, d3 d, d3 c, double r, double* t_out) {
+  double a = dlen2(d);
+  d3 oc = o - c;
+  double b = 2. * ddot(oc, d);
+  double cc = dlen2(oc) - r * r;
+  double delta = b * b - 4. * a * cc;
+  if (delta < 0.) return false;
+  double sq = sqrt(delta);
+  double t1 = (-b - sq) / (2. * a);
+  double t2 = (-b + sq) / (2. * a);
+  if (t2 < 0.) return false;
+  *t_out = t1 < 0. ? t2 : t1;
+  return true;
+}
+// Triangle::hit_info, object.rs:100-120.
+__device__ __forceinline__ bool exact_tri(d3 o, d3 d, d3 p0, d3 p1, d3 p2, double* t_out) {
+  const double EPS = 1e-3;
+  d3 e1 = p1 - p0;
+  d3 e2 = p2 - p0;
+  d3 h = dcross(d, e2);
+  double a = ddot(e1, h);
+  if (-EPS < a && a < EPS) return false;
+  double f = 1. / a;
+  d3 s = o - p0;
+  double u = f * ddot(s, h);
+  if (u < 0. || u > 1.) return false;
+  d3 q = dcross(s, e1);
+  double v = f * ddot(d, q);
+  if (v < 0. || u + v > 1.) return false;
+  double t = f * ddot(e2, q);
+  if (t > EPS) {
+    *t_out = t;
+    return true;
+  }
+  return false;
+}
+
+__device__ __forceinline__ d3 ld3(const double* p) { return d3{p[0], p[1], p[2]}; }
+
+// Exact test of global prim g for this ray and scan (motion time keyed by the owning object).
+__device__ __forceinline__ bool exact_prim(const SceneDev& S, int g, d3 o, d3 d, uint32_t scan_word,
+                                           double* t_out) {
+  if (g < S.n_sph) {
+    const double* sp = S.sphD + 4 * (size_t)g;
+    d3 c = ld3(sp);
+    if (S.any_motion) {
+      d3 mv = ld3(S.sphMvD + 3 * (size_t)g);
+      if (mv.x != 0. || mv.y != 0. || mv.z != 0.) {
+        double tm = (double)motion_time(scan_word, (uint32_t)S.prim_obj[g]);
+        c = c + mv * tm;
+      }
+    }
+    return exact_sphere(o, d, c, sp[3], t_out);
+  }
+  int ti = g - S.n_sph;
+  const double* tp = S.triD + 9 * (size_t)ti;
+  d3 p0 = ld3(tp), p1 = ld3(tp + 3), p2 = ld3(tp + 6);
+  if (S.any_motion) {
+    d3 mv = ld3(S.triMvD + 3 * (size_t)ti);
+    if (mv.x != 0. || mv.y != 0. || mv.z != 0.) {
+      double tm = (double)motion_time(scan_word, (uint32_t)S.prim_obj[g]);
+      d3 delta = mv * tm;
+      p0 = p0 + delta; p1 = p1 + delta; p2 = p2 + delta;
+    }
+  }
+  return exact_tri(o, d, p0, p1, p2, t_out);
+}
+
+// Ray::hit in f64 over every primitive (the fallback when the f32 cull cannot decide).
+// Lowest object index wins exact ties (min_by keeps the first minimum, ray.rs:23-27).
+__device__ __forceinline__ void exact_scan_all(const SceneDev& S, d3 o, d3 d, uint32_t scan_word, double* T,
+                                            int* G) {
+  double bt = __builtin_inf();
+  int bg = -1, bobj = 0x7fffffff;
+  int n = S.n_sph + S.n_tri;
+  for (int g = 0; g < n; ++g) {
+    double t;
+    if (!exact_prim(S, g, o, d, scan_word, &t)) continue;
+    int obj = S.prim_obj[g];
+    if (t < bt || (t == bt && obj < bobj)) {
+      bt = t; bg = g; bobj = obj;
+    }
+  }
+  *T = bt;
+  *G = bg;
+}
+
+// Geometric unit normal of prim g at point p (before HitInfo::new's flip):
+// sphere (p-c)/|p-c|, negated for negative radius (object.rs:288-292); triangle unit(e1 x e2) (:123).
+__device__ __forceinline__ d3 exact_normal(const SceneDev& S, int g, d3 p, uint32_t scan_word) {
+  if (g < S.n_sph) {
+    const double* sp = S.sphD + 4 * (size_t)g;
+    d3 c = ld3(sp);
+    if (S.any_motion) {
+      d3 mv = ld3(S.sphMvD + 3 * (size_t)g);
+      if (mv.x != 0. || mv.y != 0. || mv.z != 0.)
+        c = c + mv * (double)motion_time(scan_word, (uint32_t)S.prim_obj[g]);
+    }
+    d3 n = dunit(p - c);
+    if (sp[3] < 0.) n = d3{-n.x, -n.y, -n.z};
+    return n;
+  }
+  const double* tp = S.triD + 9 * (size_t)(g - S.n_sph);
+  d3 p0 = ld3(tp), p1 = ld3(tp + 3), p2 = ld3(tp + 6);
+  return dunit(dcross(p1 - p0, p2 - p0));  // translation does not change the normal
+}
+
+// ------------------------------------------------------------------ f32 cull (hot loops)
+// One sphere against one ray.  13 VALU instructions on the common (miss) path:
+// 3 sub, 3 dot, 3 fma (l = oc - b d), 3 fma (disc = r^2 - l.l), 1 compare.
+__device__ __forceinline__ void cull_sphere(float ox, float oy, float oz, float dx, float dy, float dz,
+                                            float cx, float cy, float cz, float r2, int idx,
+                                            float& best_t, int& best_i) {
+  float ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
+  float b = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
+  float lx = fmaf(-b, dx, ocx), ly = fmaf(-b, dy, ocy), lz = fmaf(-b, dz, ocz);
+  float disc = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, r2)));
+  if (disc >= 0.0f) {
+    float sq = __builtin_amdgcn_sqrtf(disc);
+    float t1 = -b - sq, t2 = sq - b;
+    float t = t1 < 0.0f ? t2 : t1;
+    if (t2 >= 0.0f && t < best_t) {
+      best_t = t;
+      best_i = idx;
+    }
+  }
+}
+
+// One triangle (p0, e1, e2) against one ray: Moller-Trumbore with slack so that borderline cases
+// reach the exact evaluation.
+__device__ __forceinline__ void cull_tri(float ox, float oy, float oz, float dx, float dy, float dz, f3 p0,
+                                         f3 e1, f3 e2, int idx, float& best_t, int& best_i) {
+  const float SLACK = 1e-4f;
+  f3 d = mk3(dx, dy, dz);
+  f3 h = cross3(d, e2);
+  float a = dot3(e1, h);
+  if (fabsf(a) > CFT_EPS * 0.99f) {
+    float f = __builtin_amdgcn_rcpf(a);
+    f3 s = mk3(ox - p0.x, oy - p0.y, oz - p0.z);
+    float u = f * dot3(s, h);
+    f3 q = cross3(s, e1);
+    float v = f * dot3(d, q);
+    float t = f * dot3(e2, q);
+    if (u >= -SLACK && v >= -SLACK && u + v <= 1.0f + SLACK && t > CFT_EPS * 0.99f && t < best_t) {
+      best_t = t;
+      best_i = idx;
+    }
+  }
+}
+
+struct Closest {
+  double t;   // exact (f64) distance, +inf on miss
+  int g;      // global prim id, -1 on miss
+};
+
+// Ray::hit for one ray.  scan_word keys the per-object motion times of this scan.
+// Counters: cnt[0] += rays that needed the f64 rescan.
+__device__ __forceinline__ Closest closest_hit(const SceneDev& S, float ox, float oy, float oz, float dx,
+                                               float dy, float dz, uint32_t scan_word, uint32_t* rescans) {
+  d3 o = d3{(double)ox, (double)oy, (double)oz};
+  d3 d = d3{(double)dx, (double)dy, (double)dz};
+  // 1. precise spheres: exact for every ray
+  double Tp = __builtin_inf();
+  int gp = -1;
+  for (int k = 0; k < S.n_prec; ++k) {
+    int g = AS_CONST(c_i32p, S.prec_gid)[k];
+    double t;
+    if (exact_prim(S, g, o, d, scan_word, &t)) {
+      if (t < Tp || (t == Tp && S.prim_obj[g] < S.prim_obj[gp])) { Tp = t; gp = g; }
+    }
+  }
+  // 2. f32 cull over everything else; anything not clearly behind the precise hit stays a candidate
+  float best_t = (gp >= 0) ? (float)Tp * (1.0f + 1e-5f) + 1e-5f : __builtin_inff();
+  int best_i = -1;   // index into the concatenation [sphF | msph | triF | mtri]
+  {
+    c_f4p sp = AS_CONST(c_f4p, S.sphF);
+    int n = S.n_sphF;
+#pragma unroll 4
+    for (int s = 0; s < n; ++s) {
+      v4f c = sp[s];
+      cull_sphere(ox, oy, oz, dx, dy, dz, c.x, c.y, c.z, c.w, s, best_t, best_i);
+    }
+  }
+  int base = S.n_sphF;
+  if (S.n_msph) {
+    c_f4p sp = AS_CONST(c_f4p, S.msphF);
+    c_f4p mv = AS_CONST(c_f4p, S.msphMv);
+    c_i32p gid = AS_CONST(c_i32p, S.msph_gid);
+    c_i32p pobj = AS_CONST(c_i32p, S.prim_obj);
+    for (int s = 0; s < S.n_msph; ++s) {
+      v4f c = sp[s];
+      v4f m = mv[s];
+      float tm = motion_time(scan_word, (uint32_t)pobj[gid[s]]);
+      cull_sphere(ox, oy, oz, dx, dy, dz, fmaf(m.x, tm, c.x), fmaf(m.y, tm, c.y), fmaf(m.z, tm, c.z), c.w,
+                  base + s, best_t, best_i);
+    }
+  }
+  base += S.n_msph;
+  {
+    c_f4p tp = AS_CONST(c_f4p, S.triF);
+    int n = S.n_triF;
+    for (int s = 0; s < n; ++s) {
+      v4f a = tp[3 * s], b = tp[3 * s + 1], c = tp[3 * s + 2];
+      cull_tri(ox, oy, oz, dx, dy, dz, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), base + s,
+               best_t, best_i);
+    }
+  }
+  base += S.n_triF;
+  if (S.n_mtri) {
+    c_f4p tp = AS_CONST(c_f4p, S.mtriF);
+    c_i32p gid = AS_CONST(c_i32p, S.mtri_gid);
+    c_i32p pobj = AS_CONST(c_i32p, S.prim_obj);
+    for (int s = 0; s < S.n_mtri; ++s) {
+      v4f a = tp[4 * s], b = tp[4 * s + 1], c = tp[4 * s + 2], m = tp[4 * s + 3];
+      float tm = motion_time(scan_word, (uint32_t)pobj[gid[s]]);
+      cull_tri(ox, oy, oz, dx, dy, dz, mk3(fmaf(m.x, tm, a.x), fmaf(m.y, tm, a.y), fmaf(m.z, tm, a.z)),
+               mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), base + s, best_t, best_i);
+    }
+  }
+  // 3. exact evaluation of the f32 winner, merged with the precise result
+  Closest r;
+  r.t = Tp;
+  r.g = gp;
+  if (best_i >= 0) {
+    int g;
+    int i = best_i;
+    if (i < S.n_sphF) g = S.sphF_gid[i];
+    else if ((i -= S.n_sphF) < S.n_msph) g = S.msph_gid[i];
+    else if ((i -= S.n_msph) < S.n_triF) g = S.triF_gid[i];
+    else g = S.mtri_gid[i - S.n_triF];
+    double t;
+    if (exact_prim(S, g, o, d, scan_word, &t)) {
+      if (gp < 0 || t < Tp || (t == Tp && S.prim_obj[g] < S.prim_obj[gp])) { r.t = t; r.g = g; }
+    } else {
+      // the f32 estimate named a primitive the exact test rejects: decide everything in f64
+      exact_scan_all(S, o, d, scan_word, &r.t, &r.g);
+      if (rescans) atomicAdd(rescans, 1u);
+    }
+  }
+  return r;
+}
+
+// ------------------------------------------------------------------ generate
+struct CamDev {   // viewport constants of Camera::emit_rays (ray.rs:112-118), computed in f64 on the host
+  float tlx, tly, tlz;      // top_left
+  float pwx, pwy, pwz;      // pw = vw/width * right
+  float phx, phy, phz;      // ph = vh/height * up
+  float px, py, pz;         // pos
+  float rx, ry, rz;         // right
+  float ux, uy, uz;         // up
+  float lens_radius;        // aperture / 2
+  uint32_t width, height;
+};
+
+__device__ __forceinline__ void primary_ray(const CamDev& C, uint64_t pid, uint32_t k0, uint32_t k1, int jitter,
+                                            f3* pos, f3* dir) {
+  uint64_t npix = (uint64_t)C.width * C.height;
+  uint32_t pix = (uint32_t)(pid % npix);
+  uint32_t w = pix % C.width, h = pix / C.width;   // image index h*WIDTH + w (scene.rs:97)
+  float urw = 0.5f, urh = 0.5f, uth = 0.0f, ur = 0.0f;
+  if (jitter) {
+    u4 r = philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), CFT_LEVEL_CAMERA, CFT_PURPOSE_CAMERA, k0, k1);
+    urw = u24f(r.x); urh = u24f(r.y); uth = u24f(r.z); ur = u24f(r.w);   // draw order rw, rh, theta, r
+  }
+  float fw = (float)w + (urw - 0.5f);
+  float fh = (float)h + (urh - 0.5f);
+  f3 to = mk3(fmaf(-fh, C.phx, fmaf(fw, C.pwx, C.tlx)), fmaf(-fh, C.phy, fmaf(fw, C.pwy, C.tly)),
+              fmaf(-fh, C.phz, fmaf(fw, C.pwz, C.tlz)));
+  float rdx, rdy;
+  gen_point_in_disk(C.lens_radius, uth, ur, &rdx, &rdy);
+  f3 from = mk3(fmaf(C.ux, rdy, fmaf(C.rx, rdx, C.px)), fmaf(C.uy, rdy, fmaf(C.ry, rdx, C.py)),
+                fmaf(C.uz, rdy, fmaf(C.rz, rdx, C.pz)));
+  *pos = from;
+  *dir = unit3(to - from);   // Ray::new normalises (ray.rs:30-35)
+}
+
+// one lane = one (pixel, sample): local path id i -> global pid = pid_base + i
+__global__ __launch_bounds__(CFT_BLOCK) void k_generate(CamDev C, uint64_t pid_base, uint32_t n, uint32_t k0,
+                                                        uint32_t k1, int jitter, QueueDev q) {
+  for (uint32_t i = blockIdx.x * CFT_BLOCK + threadIdx.x; i < n; i += gridDim.x * CFT_BLOCK) {
+    f3 pos, dir;
+    primary_ray(C, pid_base + i, k0, k1, jitter, &pos, &dir);
+    q.a[i] = make_float4(pos.x, pos.y, pos.z, dir.x);
+    q.b[i] = make_float4(dir.y, dir.z, 1.0f, 1.0f);
+    q.c[i] = make_float2(1.0f, __uint_as_float(i));
+  }
+}
+
+// ------------------------------------------------------------------ intersect
+// one lane = one live ray of trace level `level`; the primitive lists are wave-uniform operands.
+// role_a / role_b: scan numbers (motion-time keys) of the lights' `looked` scan and of trace's own
+// scan; for a static scene both scans are identical and only one is run.
+__global__ __launch_bounds__(CFT_BLOCK) void k_intersect(SceneDev S, QueueDev q, const uint32_t* counts,
+                                                         uint32_t level, uint64_t pid_base, uint32_t k0,
+                                                         uint32_t k1, uint32_t role, HitDev out,
+                                                         uint32_t* rescans) {
+  uint32_t n = counts[level];
+  for (uint32_t i = blockIdx.x * CFT_BLOCK + threadIdx.x; i < n; i += gridDim.x * CFT_BLOCK) {
+    float4 a = q.a[i];
+    float4 b = q.b[i];
+    uint32_t scan_word = 0;
+    if (S.any_motion) {
+      uint64_t pid = pid_base + __float_as_uint(q.c[i].y);
+      scan_word = philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), level, CFT_PURPOSE_SCAN0 + role, k0, k1).x;
+    }
+    Closest c = closest_hit(S, a.x, a.y, a.z, a.w, b.x, b.y, scan_word, rescans);
+    float4 h0 = make_float4(__builtin_inff(), __int_as_float(-1), 0.f, 0.f);
+    float4 h1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c.g >= 0) {
+      d3 o = d3{(double)a.x, (double)a.y, (double)a.z};
+      d3 d = d3{(double)a.w, (double)b.x, (double)b.y};
+      d3 p = o + d * c.t;                        // point = pos + dir * t
+      d3 nn = exact_normal(S, c.g, p, scan_word);
+      h0 = make_float4((float)c.t, __int_as_float(c.g), (float)p.x, (float)p.y);
+      h1 = make_float4((float)p.z, (float)nn.x, (float)nn.y, (float)nn.z);
+    }
+    out.h0[i] = h0;
+    out.h1[i] = h1;
+  }
+}
+
+// Parity hook: Ray::hit for caller rays; writes the f64 distance and the normal after HitInfo::new's
+// flip (ray.rs:233-241), all decided in f64.
+__global__ __launch_bounds__(CFT_BLOCK) void k_intersect_hook(SceneDev S, const float* rays, uint32_t n,
+                                                              uint64_t pid0, uint32_t level, uint32_t role,
+                                                              uint32_t k0, uint32_t k1, int32_t* out_id,
+                                                              double* out_t, float* out_n, float* out_p,
+                                                              uint32_t* rescans) {
+  for (uint32_t i = blockIdx.x * CFT_BLOCK + threadIdx.x; i < n; i += gridDim.x * CFT_BLOCK) {
+    const float* r = rays + 6 * (size_t)i;
+    float ox = r[0], oy = r[1], oz = r[2], dx = r[3], dy = r[4], dz = r[5];
+    uint64_t pid = pid0 + i;
+    uint32_t scan_word =
+        philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), level, CFT_PURPOSE_SCAN0 + role, k0, k1).x;
+    Closest c = closest_hit(S, ox, oy, oz, dx, dy, dz, scan_word, rescans);
+    d3 nn = d3{0., 0., 0.}, p = d3{0., 0., 0.};
+    if (c.g >= 0) {
+      d3 o = d3{(double)ox, (double)oy, (double)oz};
+      d3 d = d3{(double)dx, (double)dy, (double)dz};
+      p = o + d * c.t;
+      nn = dunit(exact_normal(S, c.g, p, scan_word));
+      d3 din = dunit(d);
+      if (ddot(nn, din) > -1e-3) nn = d3{-nn.x, -nn.y, -nn.z};
+    }
+    out_id[i] = c.g >= 0 ? S.prim_obj[c.g] : -1;
+    out_t[i] = c.t;
+    out_n[3 * (size_t)i] = (float)nn.x; out_n[3 * (size_t)i + 1] = (float)nn.y; out_n[3 * (size_t)i + 2] = (float)nn.z;
+    out_p[3 * (size_t)i] = (float)p.x; out_p[3 * (size_t)i + 1] = (float)p.y; out_p[3 * (size_t)i + 2] = (float)p.z;
+  }
+}
+
+// ------------------------------------------------------------------ shade
+struct HitInfoF {   // ray.rs:222-251 in f32
+  f3 n, p, din, dout;
+  bool outward;
+};
+__device__ __forceinline__ HitInfoF hitinfo_new(f3 norm, f3 p, f3 dir_in) {
+  HitInfoF h;
+  f3 n = unit3(norm);
+  f3 din = unit3(dir_in);
+  h.outward = dot3(n, din) > -CFT_EPS;
+  if (h.outward) n = -n;
+  f3 nu = unit3(n);                           // proj_to re-normalises its argument (util.rs:60-63)
+  f3 proj = nu * dot3(din, nu);
+  h.dout = unit3(din - proj * 2.0f);
+  h.n = n; h.p = p; h.din = din;
+  return h;
+}
+__device__ __forceinline__ f3 hi_pos(const HitInfoF& h) { return madd3(h.p, h.dout, CFT_EPS); }  // ray.rs:269-271
+__device__ __forceinline__ bool hi_refract(const HitInfoF& h, float ratio, f3* pos, f3* dir) {   // ray.rs:293-308
+  float c = dot3(h.din, h.n);
+  float disc = 1.0f - (ratio * ratio) * (1.0f - c * c);
+  if (disc > 0.0f) {
+    f3 dd = (h.din - h.n * c) * ratio - h.n * sqrtf(disc);
+    *pos = madd3(h.p, dd, CFT_EPS);
+    *dir = dd;
+    return true;
+  }
+  return false;
+}
+__device__ __forceinline__ float hi_reflect_prob(const HitInfoF& h, float ior) {  // ray.rs:312-316
+  float r0 = (1.0f - ior) / ((1.0f + ior) * (1.0f + ior));   // NOT squared, as in the reference
+  float m = 1.0f - fabsf(dot3(h.din, h.n));
+  return r0 + (1.0f - r0) * (m * m * m * m * m);
+}
+
+// Static hit of a LightShape's own shape (Shape::hit_info, no motion), f64: light shapes are few.
+__device__ __forceinline__ bool light_shape_hit(const SceneDev& S, const LightDev& L, f3 pos, f3 dir, double* t_out) {
+  d3 o = d3{(double)pos.x, (double)pos.y, (double)pos.z};
+  d3 d = d3{(double)dir.x, (double)dir.y, (double)dir.z};
+  double bt = __builtin_inf();
+  bool any = false;
+  for (int k = 0; k < L.sph_count; ++k) {
+    const double* sp = S.lsphD + 4 * (size_t)(L.sph_begin + k);
+    double t;
+    if (exact_sphere(o, d, ld3(sp), sp[3], &t) && t < bt) { bt = t; any = true; }
+  }
+  for (int k = 0; k < L.tri_count; ++k) {
+    const double* tp = S.ltriD + 9 * (size_t)(L.tri_begin + k);
+    double t;
+    if (exact_tri(o, d, ld3(tp), ld3(tp + 3), ld3(tp + 6), &t) && t < bt) { bt = t; any = true; }
+  }
+  *t_out = bt;
+  return any;
+}
+
+struct PhongQueueDev {   // Phong hits handed to k_shadow: 64 B per entry
+  float4* a;   // px, py, pz, nx
+  float4* b;   // ny, nz, doutx, douty
+  float4* c;   // doutz, thr_r, thr_g, thr_b
+  uint2* d;    // path id, material id
+};
+
+// one lane = one (ray, hit) record of this level.  hitA = the lights' `looked` scan, hitB = trace's
+// own scan (the same buffers for a static scene).
+__global__ __launch_bounds__(CFT_BLOCK) void k_shade(SceneDev S, QueueDev qin, HitDev hitA, HitDev hitB,
+                                                     uint32_t* counts, uint32_t level, uint32_t max_depth,
+                                                     uint64_t pid_base, uint32_t k0, uint32_t k1, QueueDev qout,
+                                                     float4* radiance, PhongQueueDev pq, uint32_t* phong_counts) {
+  uint32_t n = counts[level];
+  uint32_t nround = (n + 63u) & ~63u;
+  for (uint32_t i = blockIdx.x * CFT_BLOCK + threadIdx.x; i < nround; i += gridDim.x * CFT_BLOCK) {
+    bool live = i < n;
+    bool alive = false;          // continues to the next level
+    f3 npos = mk3(0, 0, 0), ndir = mk3(0, 0, 0), thr = mk3(0, 0, 0);
+    uint32_t lpid = 0;
+    if (live) {
+      float4 a = qin.a[i];
+      float4 b = qin.b[i];
+      float2 c = qin.c[i];
+      f3 pos = mk3(a.x, a.y, a.z), dir = mk3(a.w, b.x, b.y);
+      thr = mk3(b.z, b.w, c.x);
+      lpid = __float_as_uint(c.y);
+      float4 A0 = hitA.h0[i];
+      int primA = __float_as_int(A0.y);
+      // ---- lights: LightSource::looked (object.rs:333-341)
+      bool see = false;
+      f3 col = mk3(0, 0, 0);
+      for (int l = 0; l < S.n_lights; ++l) {
+        const LightDev L = S.lights[l];
+        if (L.kind == 0) {                       // SkyLight::looked, light.rs:184-190
+          if (primA < 0) { see = true; col = col + sky_color_from(dir); }
+        } else if (L.kind == 1) {                // LightShape::looked, light.rs:233-242
+          double tl;
+          if (light_shape_hit(S, L, pos, dir, &tl)) {
+            if (primA < 0 || tl < (double)A0.x) { see = true; col = col + mk3(L.r, L.g, L.b); }
+          }
+        }
+      }
+      if (see) {
+        radiance[lpid] = make_float4(thr.x * col.x, thr.y * col.y, thr.z * col.z, 0.f);
+      } else {
+        float4 B0 = hitB.h0[i];
+        int prim = __float_as_int(B0.y);
+        if (prim < 0) {
+          radiance[lpid] = make_float4(0.f, 0.f, 0.f, 0.f);   // object.rs:354
+        } else {
+          float4 B1 = hitB.h1[i];
+          HitInfoF h = hitinfo_new(mk3(B1.y, B1.z, B1.w), mk3(B0.z, B0.w, B1.x), dir);
+          const MatDev m = S.mats[S.prim_mat[prim]];
+          uint64_t pid = pid_base + lpid;
+          f3 k = mk3(1, 1, 1);
+          bool scattered = true;
+          switch (m.kind) {
+            case 0: {   // LambertianModel, compose.rs:110-119
+              u4 r = philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), level, CFT_PURPOSE_SCATTER, k0, k1);
+              npos = hi_pos(h);
+              ndir = unit3(h.dout + gen_point_in_sphere(1.0f, u24f(r.x), u24f(r.y)));
+              k = mk3(m.r * m.p0, m.g * m.p0, m.b * m.p0);
+            } break;
+            case 1: {   // Metal, compose.rs:42-52
+              u4 r = philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), level, CFT_PURPOSE_SCATTER, k0, k1);
+              npos = hi_pos(h);
+              ndir = unit3(h.dout + gen_point_in_sphere(m.p0, u24f(r.x), u24f(r.y)));
+              k = mk3(m.p1 * m.r, m.p1 * m.g, m.p1 * m.b);
+            } break;
+            case 2: {   // Dielectric, compose.rs:74-88
+              u4 r = philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), level, CFT_PURPOSE_SCATTER, k0, k1);
+              bool refl = u24f(r.x) < hi_reflect_prob(h, m.p0);
+              if (!refl) {
+                float ratio = h.outward ? m.p0 : 1.0f / m.p0;
+                refl = !hi_refract(h, ratio, &npos, &ndir);   // total reflection -> reflect
+              }
+              if (refl) { npos = hi_pos(h); ndir = h.dout; }
+            } break;
+            case 4: {   // Specular, basic.rs:120-124 (default scatter = reflect)
+              npos = hi_pos(h); ndir = h.dout;
+              k = mk3(m.p0, m.p0, m.p0);
+            } break;
+            case 5: {   // Transparent, basic.rs:168-184
+              float ratio = h.outward ? m.p1 : 1.0f / m.p1;
+              if (!hi_refract(h, ratio, &npos, &ndir)) { npos = hi_pos(h); ndir = h.dout; }
+              float s = 1.0f - m.p0;
+              k = mk3(m.r * s, m.g * s, m.b * s);
+            } break;
+            default: {  // PhongModel: terminal, handed to k_shadow
+              scattered = false;
+              uint32_t slot = atomicAdd(&phong_counts[level], 1u);
+              pq.a[slot] = make_float4(h.p.x, h.p.y, h.p.z, h.n.x);
+              pq.b[slot] = make_float4(h.n.y, h.n.z, h.dout.x, h.dout.y);
+              pq.c[slot] = make_float4(h.dout.z, thr.x, thr.y, thr.z);
+              pq.d[slot] = make_uint2(lpid, (uint32_t)S.prim_mat[prim]);
+            } break;
+          }
+          if (scattered) {
+            thr = thr * k;
+            if (level + 1 < max_depth) alive = true;
+            else radiance[lpid] = make_float4(0.f, 0.f, 0.f, 0.f);   // trace(.., 0) is black (object.rs:327-329)
+          }
+        }
+      }
+    }
+    // ---- compacted enqueue: one atomic per wave (ballot + prefix count)
+    unsigned long long mask = __ballot(alive);
+    if (mask) {
+      uint32_t cnt = (uint32_t)__popcll(mask);
+      uint32_t lane = threadIdx.x & 63u;
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&counts[level + 1], cnt);
+      base = __shfl(base, 0);
+      if (alive) {
+        uint32_t off = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        uint32_t s = base + off;
+        qout.a[s] = make_float4(npos.x, npos.y, npos.z, ndir.x);
+        qout.b[s] = make_float4(ndir.y, ndir.z, thr.x, thr.y);
+        qout.c[s] = make_float2(thr.z, __uint_as_float(lpid));
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ shadow (PhongModel::render)
+// one lane = one Phong hit; loops over the lights (basic.rs:57-94).  Every (hit, light) pair scans
+// one ray against the world: the mirror ray (sky / shape lights) or the ray towards the light
+// (point / parallel lights).
+__global__ __launch_bounds__(CFT_BLOCK) void k_shadow(SceneDev S, PhongQueueDev pq, const uint32_t* phong_counts,
+                                                      uint32_t level, uint64_t pid_base, uint32_t k0, uint32_t k1,
+                                                      float4* radiance, uint32_t* rescans) {
+  uint32_t n = phong_counts[level];
+  uint32_t nl = (uint32_t)S.n_lights;
+  for (uint32_t i = blockIdx.x * CFT_BLOCK + threadIdx.x; i < n; i += gridDim.x * CFT_BLOCK) {
+    float4 a = pq.a[i], b = pq.b[i], c = pq.c[i];
+    uint2 dd = pq.d[i];
+    f3 p = mk3(a.x, a.y, a.z), nrm = mk3(a.w, b.x, b.y), dout = mk3(b.z, b.w, c.x);
+    f3 thr = mk3(c.y, c.z, c.w);
+    const MatDev m = S.mats[dd.y];
+    uint64_t pid = pid_base + dd.x;
+    f3 pos = madd3(p, dout, CFT_EPS);   // hit.pos()
+    f3 sum = mk3(0, 0, 0);
+    for (uint32_t j = 0; j < nl; ++j) {
+      const LightDev L = S.lights[j];
+      uint32_t wl = 0, ws = 0;
+      if (S.any_motion) {
+        wl = philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), level, CFT_PURPOSE_SCAN0 + nl + 1 + 2 * j, k0, k1).x;
+        ws = philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), level, CFT_PURPOSE_SCAN0 + nl + 2 + 2 * j, k0, k1).x;
+      }
+      f3 ldir, lcol;
+      float inten;
+      bool shadow;
+      if (L.kind == 0) {            // SkyLight
+        Closest hl = closest_hit(S, pos.x, pos.y, pos.z, dout.x, dout.y, dout.z, wl, rescans);
+        if (hl.g < 0) { sum = sum + sky_color_from(dout); continue; }     // looked(reflect) -> return c
+        ldir = -dout; lcol = sky_color_from(dout); inten = 1.0f;
+        if (S.any_motion) shadow = closest_hit(S, pos.x, pos.y, pos.z, dout.x, dout.y, dout.z, ws, rescans).g >= 0;
+        else shadow = true;         // same ray, same static world: it hit
+      } else if (L.kind == 1) {     // LightShape
+        double tl;
+        bool hs = light_shape_hit(S, L, pos, dout, &tl);
+        Closest hw = closest_hit(S, pos.x, pos.y, pos.z, dout.x, dout.y, dout.z, wl, rescans);
+        if (hs && (hw.g < 0 || tl < hw.t)) { sum = sum + mk3(L.r, L.g, L.b); continue; }
+        ldir = -dout; lcol = mk3(L.r, L.g, L.b); inten = hs ? 1.0f : 0.0f;
+        Closest h2 = S.any_motion ? closest_hit(S, pos.x, pos.y, pos.z, dout.x, dout.y, dout.z, ws, rescans) : hw;
+        shadow = h2.g >= 0 && hs && h2.t < tl;
+      } else if (L.kind == 2) {     // PointLight, light.rs:111-135
+        f3 lp = mk3(L.vx, L.vy, L.vz);
+        ldir = unit3(pos - lp);
+        lcol = mk3(L.r, L.g, L.b);
+        f3 dl = lp - pos;
+        inten = 1.0f / dot3(dl, dl);
+        f3 rd = unit3(-ldir);
+        Closest hw = closest_hit(S, pos.x, pos.y, pos.z, rd.x, rd.y, rd.z, ws, rescans);
+        shadow = false;
+        if (hw.g >= 0) {
+          float t = (float)hw.t;
+          f3 hp = madd3(pos, rd, t) - pos;                 // point - hit.pos() (un-offset hit point)
+          float l1 = dot3(hp, hp), l2 = dot3(dl, dl);
+          shadow = l1 + CFT_EPS < l2;
+        }
+      } else {                      // ParallelLight, light.rs:86-102
+        ldir = mk3(L.vx, L.vy, L.vz);
+        lcol = mk3(L.r, L.g, L.b);
+        inten = 1.0f;
+        f3 rd = unit3(-ldir);
+        shadow = closest_hit(S, pos.x, pos.y, pos.z, rd.x, rd.y, rd.z, ws, rescans).g >= 0;
+      }
+      float ratio2 = dot3(dout, -ldir);
+      float ratio = powf(ratio2, m.p0);
+      ratio = (ratio < 1.0f) ? ratio : 1.0f;     // min!(ratio, 1.): NaN -> 1
+      ratio = (ratio > 0.0f) ? ratio : 0.0f;     // max!(ratio, 0.)
+      float dn = dot3(nrm, -ldir);
+      float di = (dn > 0.0f) ? dn : 0.0f;
+      float w = shadow ? 0.1f : (ratio * 0.5f + di * 0.5f + 0.1f);
+      sum = madd3(sum, lcol, inten * w);
+    }
+    f3 outc = mk3(m.p1 * sum.x * m.r, m.p1 * sum.y * m.g, m.p1 * sum.z * m.b);   // kd * c * color
+    radiance[dd.x] = make_float4(thr.x * outc.x, thr.y * outc.y, thr.z * outc.z, 0.f);
+  }
+}
+
+// ------------------------------------------------------------------ resolve
+// one lane = one pixel: accum[pix] += sum over the pass's samples, in sample order (deterministic).
+__global__ __launch_bounds__(CFT_BLOCK) void k_resolve(const float4* radiance, uint32_t npix, uint32_t nsamples,
+                                                       float* accum) {
+  for (uint32_t p = blockIdx.x * CFT_BLOCK + threadIdx.x; p < npix; p += gridDim.x * CFT_BLOCK) {
+    float r = 0.f, g = 0.f, b = 0.f;
+    for (uint32_t s = 0; s < nsamples; ++s) {
+      float4 v = radiance[(size_t)s * npix + p];
+      r += v.x; g += v.y; b += v.z;
+    }
+    accum[3 * (size_t)p] += r;
+    accum[3 * (size_t)p + 1] += g;
+    accum[3 * (size_t)p + 2] += b;
+  }
+}
+
+// vec3_to_rgb, scene.rs:122-127
+__global__ __launch_bounds__(CFT_BLOCK) void k_rgb8(const float* accum, uint64_t n, float div, uint8_t* out) {
+  for (uint64_t i = blockIdx.x * (uint64_t)CFT_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * CFT_BLOCK) {
+    float c = accum[i] / div;
+    float m = (1.0f < c) ? 1.0f : c;
+    float x = (0.0f > m) ? 0.0f : m;
+    out[i] = (uint8_t)(255.99f * sqrtf(x));
+  }
+}

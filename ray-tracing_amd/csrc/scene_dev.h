@@ -1,0 +1,74 @@
+// scene_dev.h — the flattened scene as it lives in HBM (structure-of-arrays primitive buffers,
+// packed material table, light list).  Passed to kernels by value (kernarg).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct MatDev {   // packed material table row (32 B); kinds as in cftrt.h
+  int kind;
+  float p0, p1;
+  float r, g, b;
+  float pad0, pad1;
+};
+
+struct LightDev {  // device light list row
+  int kind;
+  int sph_begin, sph_count;
+  int tri_begin, tri_count;
+  float vx, vy, vz;   // pos (point) / dir (parallel)
+  float r, g, b;
+};
+
+// Primitive ids.  A "global prim id" g names one primitive of the input arrays:
+//   g in [0, n_sph)            -> sphere g
+//   g in [n_sph, n_sph+n_tri)  -> triangle g - n_sph
+// prim_obj[g] is the owning object's index in world.objects (the parity "object id").
+struct SceneDev {
+  // ---- f32 cull lists (hot loops) ----
+  const float4* sphF;     // static, non-precise spheres: (cx, cy, cz, r^2)
+  const int* sphF_gid;    // -> global prim id
+  int n_sphF;
+  const float4* msphF;    // moving spheres: (cx, cy, cz, r^2) at time 0
+  const float4* msphMv;   // (mvx, mvy, mvz, 0)
+  const int* msph_gid;
+  int n_msph;
+  const int* prec_gid;    // "precise" spheres (|r| >= precise_radius): exact f64 test for every ray
+  int n_prec;
+  const float4* triF;     // static triangles, 3 float4 each: (p0, -), (e1, -), (e2, -)
+  const int* triF_gid;
+  int n_triF;
+  const float4* mtriF;    // moving triangles, 4 float4 each: p0, e1, e2, mv
+  const int* mtri_gid;
+  int n_mtri;
+  // ---- f64 master copies (exact evaluation) ----
+  const double* sphD;     // n_sph x 4: cx, cy, cz, r
+  const double* sphMvD;   // n_sph x 3 (all zero for static spheres)
+  int n_sph;
+  const double* triD;     // n_tri x 9: p0, p1, p2
+  const double* triMvD;   // n_tri x 3
+  int n_tri;
+  // ---- per-prim tables ----
+  const int* prim_obj;
+  const int* prim_mat;
+  const MatDev* mats;
+  int n_mat;
+  // ---- lights ----
+  const LightDev* lights;
+  int n_lights;
+  const double* lsphD;    // light-shape spheres, 4 each
+  const double* ltriD;    // light-shape triangles, 9 each
+  int any_motion;
+  int n_phong_mats;
+};
+
+// Ray queue slot: 40 B in three coalesced streams.
+struct QueueDev {
+  float4* a;   // ox, oy, oz, dx
+  float4* b;   // dy, dz, thr_r, thr_g
+  float2* c;   // thr_b, path id (uint bits)
+};
+// Hit record: 32 B in two streams.
+struct HitDev {
+  float4* h0;  // t, prim (int bits; -1 = miss), px, py
+  float4* h1;  // pz, nx, ny, nz   (geometric unit normal before HitInfo::new's flip)
+};
