@@ -17,6 +17,7 @@ into the SoA arrays the device wants; user-defined impls have no device counterp
 """
 import ctypes as C
 import math
+import weakref
 
 import numpy as np
 
@@ -67,6 +68,7 @@ class Square:
 
     def __init__(self, center, x, y, len):
         center, x, y = _v(center), _v(x), _v(y)
+        self._ctor = (center, x, y, float(len))
         x2 = v_div(v_mul(x, float(len)), 2.0)
         y2 = v_div(v_mul(y, float(len)), 2.0)
         p0 = v_add(v_sub(center, x2), y2)
@@ -79,6 +81,7 @@ class Square:
     @classmethod
     def from_points(cls, p0, p1, p2, p3):  # object.rs:169-174
         s = cls.__new__(cls)
+        s._ctor = None
         s.tri0 = Triangle(p0, p1, p2)
         s.tri1 = Triangle(p1, p2, p3)
         return s
@@ -336,6 +339,7 @@ class Device:
             raise L.CftrtError(rc, self.lib.cftrt_last_error(None).decode())
         self.h = h
         self.index = index
+        self._worlds = weakref.WeakSet()   # worlds with a scene on this ctx: destroyed before the ctx
 
     def check(self, rc):
         if rc != 0:
@@ -349,6 +353,8 @@ class Device:
 
     def close(self):
         if getattr(self, "h", None):
+            for w in list(self._worlds):
+                w._invalidate()
             self.lib.cftrt_ctx_destroy(self.h)
             self.h = None
 
@@ -413,7 +419,8 @@ class World:
 
     def _invalidate(self):
         if self._scene is not None:
-            self._dev.lib.cftrt_scene_destroy(self._scene)
+            if self._dev.h is not None:
+                self._dev.lib.cftrt_scene_destroy(self._scene)
             self._scene = None
 
     # -- flattening: trait objects -> SoA primitive buffers + material table + light list
@@ -503,6 +510,7 @@ class World:
             lib.cftrt_scene_destroy(h)
             raise
         self._scene, self._dev = h, dev
+        dev._worlds.add(self)
         return h
 
     # -- the batched entry point: the loop scene.rs:91-102 / cornell.rs:32-39 hand-roll

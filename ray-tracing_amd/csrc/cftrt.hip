@@ -335,6 +335,9 @@ int cftrt_scene_commit(cftrt_scene* s) {
       triF_gid.push_back(ns + i);
     }
   }
+  const int n_sphF_real = (int)sphF_gid.size();
+  while (sphF.size() % 4) sphF.push_back(make_float4(0.f, 0.f, 0.f, -1.f));   // never hit: disc = -1 - |l|^2
+  for (int k = 0; k < 4; ++k) sphF.push_back(make_float4(0.f, 0.f, 0.f, -1.f));   // the prefetched extra batch
   std::vector<MatDev> mats(nm);
   int n_phong = 0;
   for (int i = 0; i < nm; ++i) {
@@ -372,7 +375,7 @@ int cftrt_scene_commit(cftrt_scene* s) {
   if ((rc = upload(s, lights, &D.lights))) return rc;
   if ((rc = upload(s, s->lsph, &D.lsphD))) return rc;
   if ((rc = upload(s, s->ltri, &D.ltriD))) return rc;
-  D.n_sphF = (int)sphF_gid.size();
+  D.n_sphF = n_sphF_real;
   D.n_msph = (int)msph_gid.size();
   D.n_prec = (int)prec_gid.size();
   D.n_triF = (int)triF_gid.size();

@@ -18,10 +18,13 @@
 #include "scene_dev.h"
 
 #define CFT_BLOCK 256
+#define CFT_SHADE_CHUNK 1024
 
 // constant-address-space views: a wave-uniform index then compiles to s_load (SGPR operands)
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef const v4f __attribute__((address_space(4))) * c_f4p;
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef const v16f __attribute__((address_space(4))) * c_f16p;
 typedef const int __attribute__((address_space(4))) * c_i32p;
 typedef const double __attribute__((address_space(4))) * c_f64p;
 #define AS_CONST(T, p) ((T)(uintptr_t)(p))
@@ -219,12 +222,19 @@ __device__ __forceinline__ Closest closest_hit(const SceneDev& S, float ox, floa
   float best_t = (gp >= 0) ? (float)Tp * (1.0f + 1e-5f) + 1e-5f : __builtin_inff();
   int best_i = -1;   // index into the concatenation [sphF | msph | triF | mtri]
   {
-    c_f4p sp = AS_CONST(c_f4p, S.sphF);
-    int n = S.n_sphF;
-#pragma unroll 4
-    for (int s = 0; s < n; ++s) {
-      v4f c = sp[s];
-      cull_sphere(ox, oy, oz, dx, dy, dz, c.x, c.y, c.z, c.w, s, best_t, best_i);
+    // 4 spheres per s_load_dwordx16, fetched one batch ahead; the array is padded on the host with
+    // never-hit spheres (r^2 = -1) to a multiple of 4 plus one extra batch.
+    c_f16p sp = AS_CONST(c_f16p, S.sphF);
+    const int n4 = (S.n_sphF + 3) >> 2;
+    v16f cur = sp[0];
+    for (int s4 = 0; s4 < n4; ++s4) {
+      v16f nxt = sp[s4 + 1];
+      const int s = s4 << 2;
+      cull_sphere(ox, oy, oz, dx, dy, dz, cur[0], cur[1], cur[2], cur[3], s, best_t, best_i);
+      cull_sphere(ox, oy, oz, dx, dy, dz, cur[4], cur[5], cur[6], cur[7], s + 1, best_t, best_i);
+      cull_sphere(ox, oy, oz, dx, dy, dz, cur[8], cur[9], cur[10], cur[11], s + 2, best_t, best_i);
+      cull_sphere(ox, oy, oz, dx, dy, dz, cur[12], cur[13], cur[14], cur[15], s + 3, best_t, best_i);
+      cur = nxt;
     }
   }
   int base = S.n_sphF;
@@ -463,9 +473,20 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_shade(SceneDev S, QueueDev qin, H
                                                      uint32_t* counts, uint32_t level, uint32_t max_depth,
                                                      uint64_t pid_base, uint32_t k0, uint32_t k1, QueueDev qout,
                                                      float4* radiance, PhongQueueDev pq, uint32_t* phong_counts) {
-  uint32_t n = counts[level];
-  uint32_t nround = (n + 63u) & ~63u;
-  for (uint32_t i = blockIdx.x * CFT_BLOCK + threadIdx.x; i < nround; i += gridDim.x * CFT_BLOCK) {
+  // Survivors of a 1024-ray chunk are staged in LDS and appended to the next queue with ONE global
+  // atomic per chunk (a returning atomic on one word saturates near 88/us chip-wide, which a
+  // per-wave atomic would hit at ~2M waves per level), then copied out coalesced.
+  __shared__ float4 s_a[CFT_SHADE_CHUNK];
+  __shared__ float4 s_b[CFT_SHADE_CHUNK];
+  __shared__ float2 s_c[CFT_SHADE_CHUNK];
+  __shared__ uint32_t s_cnt, s_base;
+  const uint32_t n = counts[level];
+  const uint32_t nchunks = (n + CFT_SHADE_CHUNK - 1) / CFT_SHADE_CHUNK;
+  for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+   if (threadIdx.x == 0) s_cnt = 0;
+   __syncthreads();
+   for (uint32_t rr = 0; rr < CFT_SHADE_CHUNK / CFT_BLOCK; ++rr) {
+    uint32_t i = chunk * CFT_SHADE_CHUNK + rr * CFT_BLOCK + threadIdx.x;
     bool live = i < n;
     bool alive = false;          // continues to the next level
     f3 npos = mk3(0, 0, 0), ndir = mk3(0, 0, 0), thr = mk3(0, 0, 0);
@@ -556,22 +577,34 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_shade(SceneDev S, QueueDev qin, H
         }
       }
     }
-    // ---- compacted enqueue: one atomic per wave (ballot + prefix count)
+    // ---- stage survivors in LDS: one LDS atomic per wave (ballot + prefix count)
     unsigned long long mask = __ballot(alive);
     if (mask) {
       uint32_t cnt = (uint32_t)__popcll(mask);
       uint32_t lane = threadIdx.x & 63u;
       uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(&counts[level + 1], cnt);
+      if (lane == 0) base = atomicAdd(&s_cnt, cnt);
       base = __shfl(base, 0);
       if (alive) {
         uint32_t off = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
         uint32_t s = base + off;
-        qout.a[s] = make_float4(npos.x, npos.y, npos.z, ndir.x);
-        qout.b[s] = make_float4(ndir.y, ndir.z, thr.x, thr.y);
-        qout.c[s] = make_float2(thr.z, __uint_as_float(lpid));
+        s_a[s] = make_float4(npos.x, npos.y, npos.z, ndir.x);
+        s_b[s] = make_float4(ndir.y, ndir.z, thr.x, thr.y);
+        s_c[s] = make_float2(thr.z, __uint_as_float(lpid));
       }
     }
+   }
+   __syncthreads();
+   const uint32_t nb = s_cnt;
+   if (threadIdx.x == 0 && nb) s_base = atomicAdd(&counts[level + 1], nb);
+   __syncthreads();
+   const uint32_t gb = s_base;
+   for (uint32_t k = threadIdx.x; k < nb; k += CFT_BLOCK) {
+     qout.a[gb + k] = s_a[k];
+     qout.b[gb + k] = s_b[k];
+     qout.c[gb + k] = s_c[k];
+   }
+   __syncthreads();
   }
 }
 

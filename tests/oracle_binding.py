@@ -1,0 +1,189 @@
+"""ctypes binding of oracle/liboracle.so — the CPU restatement of the reference (TEST INFRASTRUCTURE:
+only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it)."""
+import ctypes as C
+import importlib
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+
+
+class orc_camera(C.Structure):
+    _fields_ = [("frm", C.c_double * 3), ("to", C.c_double * 3), ("focus_dist", C.c_double),
+                ("aperture", C.c_double), ("fov_rad", C.c_double), ("aspect", C.c_double)]
+
+
+_lib = None
+_D = C.POINTER(C.c_double)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"])
+        L = C.CDLL(LIB_PATH)
+        L.orc_world_new.restype = C.c_void_p
+        L.orc_world_free.argtypes = [C.c_void_p]
+        L.orc_add_material.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, _D]
+        L.orc_add_sphere.argtypes = [C.c_void_p, _D, C.c_double, C.c_int, _D]
+        L.orc_add_triangle.argtypes = [C.c_void_p, _D, _D, _D, C.c_int, _D]
+        L.orc_add_square.argtypes = [C.c_void_p, _D, _D, _D, C.c_double, C.c_int, _D]
+        L.orc_add_cube.argtypes = [C.c_void_p, _D, _D, _D, C.c_double, C.c_int, _D]
+        L.orc_add_sky.argtypes = [C.c_void_p]
+        L.orc_add_point_light.argtypes = [C.c_void_p, _D, _D]
+        L.orc_add_parallel_light.argtypes = [C.c_void_p, _D, _D]
+        L.orc_add_light_shape.argtypes = [C.c_void_p, C.c_int, _D, _D, _D, C.c_double]
+        L.orc_camera_basis.argtypes = [C.POINTER(orc_camera), _D, _D, _D, _D]
+        L.orc_emit_rays.argtypes = [C.POINTER(orc_camera), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
+                                    C.c_uint64, C.c_int, _D]
+        L.orc_hit.argtypes = [C.c_void_p, _D, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
+                              C.POINTER(C.c_int32), _D, _D, _D, C.POINTER(C.c_int32)]
+        L.orc_trace_paths.restype = C.c_uint64
+        L.orc_trace_paths.argtypes = [C.c_void_p, C.POINTER(orc_camera), C.c_uint64, C.c_uint64, C.c_uint64,
+                                      C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, _D]
+        L.orc_render.restype = C.c_uint64
+        L.orc_render.argtypes = [C.c_void_p, C.POINTER(orc_camera), C.c_uint64, C.c_uint64, C.c_uint64,
+                                 C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, _D]
+        L.orc_to_rgb8.argtypes = [_D, C.c_uint64, C.c_double, C.POINTER(C.c_uint8)]
+        L.orc_philox.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.orc_lowbias32.restype = C.c_uint32
+        L.orc_lowbias32.argtypes = [C.c_uint32]
+        L.orc_vec3_op.argtypes = [C.c_int, _D, _D, C.c_double, _D]
+        L.orc_gen_point_in_sphere.argtypes = [C.c_double, C.c_double, C.c_double, _D]
+        L.orc_gen_point_in_disk.argtypes = [C.c_double, C.c_double, C.c_double, _D]
+        L.orc_shape_hit_info.argtypes = [C.c_int, _D, _D, _D, C.c_double, _D, _D, C.c_int, _D]
+        L.orc_tri_is_in_plane.argtypes = [_D, _D, _D, _D]
+        L.orc_tri_contain.argtypes = [_D, _D, _D, _D]
+        L.orc_hitinfo_refract.argtypes = [_D, _D, _D, C.c_double, _D]
+        L.orc_hitinfo_reflect_prob.restype = C.c_double
+        L.orc_hitinfo_reflect_prob.argtypes = [_D, _D, C.c_double]
+        L.orc_sky_color.argtypes = [_D, _D]
+        L.orc_min_macro.restype = C.c_double
+        L.orc_min_macro.argtypes = [_D, C.c_int]
+        L.orc_max_macro.restype = C.c_double
+        L.orc_max_macro.argtypes = [_D, C.c_int]
+        _lib = L
+    return _lib
+
+
+def d3(v):
+    return (C.c_double * 3)(*[float(x) for x in v])
+
+
+def vec3_op(op, a, b=None, s=0.0):
+    out = (C.c_double * 3)()
+    lib().orc_vec3_op(op, d3(a), d3(b) if b is not None else None, float(s), out)
+    return np.array(out[:])
+
+
+def camera_pod(cam):
+    """cam: the host mirror Camera (pos, sight after look(), builder fields)."""
+    c = orc_camera()
+    c.frm[:] = cam.pos
+    # the oracle re-runs Camera::new(from, to): any point along sight reproduces the same basis
+    c.to[:] = tuple(p + s for p, s in zip(cam.pos, cam.sight))
+    c.focus_dist, c.aperture, c.fov_rad, c.aspect = cam.focus_dist, cam.aperture, cam.fov, cam.aspect
+    return c
+
+
+class OracleWorld:
+    """Builds the oracle's World from the host-mirror World WITHOUT flattening: cubes stay cubes and
+    squares stay squares, so the product's flattening is itself under test."""
+
+    def __init__(self, world):
+        rt = importlib.import_module("ray-tracing_amd")
+        A = rt.api
+        L = lib()
+        self.h = C.c_void_p(L.orc_world_new())
+        self.n_objects = len(world.objects)
+        for o in world.objects:
+            kind, p0, p1, col = o.material._row()
+            mid = L.orc_add_material(self.h, kind, p0, p1, d3(col))
+            assert mid >= 0
+            mv = d3(o.moving_to)
+            s = o.shape
+            if isinstance(s, A.Sphere):
+                L.orc_add_sphere(self.h, d3(s.center), s.radius, mid, mv)
+            elif isinstance(s, A.Triangle):
+                L.orc_add_triangle(self.h, d3(s.p0), d3(s.p1), d3(s.p2), mid, mv)
+            elif isinstance(s, A.Cube):
+                L.orc_add_cube(self.h, d3(s.center), d3(s.x), d3(s.y), s.len, mid, mv)
+            elif isinstance(s, A.Square):
+                if s._ctor is None:
+                    raise TypeError("Square.from_points has no oracle constructor")
+                a = s._ctor
+                L.orc_add_square(self.h, d3(a[0]), d3(a[1]), d3(a[2]), a[3], mid, mv)
+            else:
+                raise TypeError(type(s))
+        for l in world.lights:
+            if l.kind == 0:
+                L.orc_add_sky(self.h)
+            elif l.kind == 2:
+                L.orc_add_point_light(self.h, d3(l.pos), d3(l.light_color))
+            elif l.kind == 3:
+                L.orc_add_parallel_light(self.h, d3(l.dir), d3(l.light_color))
+            else:
+                s = l.shape
+                if isinstance(s, A.Sphere):
+                    L.orc_add_light_shape(self.h, 0, d3(s.center), d3((0, 0, 0)), d3((0, 0, 0)), s.radius)
+                elif isinstance(s, A.Triangle):
+                    L.orc_add_light_shape(self.h, 1, d3(s.p0), d3(s.p1), d3(s.p2), 0.0)
+                elif isinstance(s, A.Cube):
+                    L.orc_add_light_shape(self.h, 3, d3(s.center), d3(s.x), d3(s.y), s.len)
+                else:
+                    a = s._ctor
+                    L.orc_add_light_shape(self.h, 2, d3(a[0]), d3(a[1]), d3(a[2]), a[3])
+
+    def __del__(self):
+        try:
+            lib().orc_world_free(self.h)
+        except Exception:
+            pass
+
+    def hit(self, rays, seed=0, pid0=0, level=0, role=0):
+        rays = np.ascontiguousarray(rays, np.float64).reshape(-1, 6)
+        n = len(rays)
+        ids = np.empty(n, np.int32)
+        t = np.empty(n, np.float64)
+        nrm = np.empty((n, 3), np.float64)
+        pt = np.empty((n, 3), np.float64)
+        fl = np.empty(n, np.int32)
+        lib().orc_hit(self.h, rays.ctypes.data_as(_D), n, seed, pid0, level, role,
+                      ids.ctypes.data_as(C.POINTER(C.c_int32)), t.ctypes.data_as(_D), nrm.ctypes.data_as(_D),
+                      pt.ctypes.data_as(_D), fl.ctypes.data_as(C.POINTER(C.c_int32)))
+        return ids, t, nrm, pt, fl
+
+    def trace_paths(self, cam, width, height, pid0, n, depth, seed, jitter=True):
+        out = np.empty((n, 3), np.float64)
+        pod = camera_pod(cam)
+        rays = lib().orc_trace_paths(self.h, C.byref(pod), width, height, pid0, n, depth, seed, int(jitter),
+                                     out.ctypes.data_as(_D))
+        return out, rays
+
+    def render(self, cam, width, height, depth, seed, spp_begin=0, spp_end=None, nthreads=8):
+        if spp_end is None:
+            spp_end = spp_begin + cam.sample_rate
+        acc = np.zeros((height, width, 3), np.float64)
+        pod = camera_pod(cam)
+        rays = lib().orc_render(self.h, C.byref(pod), width, height, spp_begin, spp_end, depth, seed, nthreads,
+                                acc.ctypes.data_as(_D))
+        return acc, rays
+
+
+def emit_rays(cam, width, height, pid0, n, seed, jitter=True):
+    out = np.empty((n, 6), np.float64)
+    pod = camera_pod(cam)
+    lib().orc_emit_rays(C.byref(pod), width, height, pid0, n, seed, int(jitter), out.ctypes.data_as(_D))
+    return out
+
+
+def to_rgb8(accum, divisor):
+    accum = np.ascontiguousarray(accum, np.float64)
+    out = np.empty(accum.shape, np.uint8)
+    lib().orc_to_rgb8(accum.ctypes.data_as(_D), accum.size // 3, float(divisor), out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
