@@ -292,6 +292,7 @@ class Camera:
         return c
 
     def look(self, point):  # ray.rs:85-89
+        self._to = _v(point)
         self.sight = v_unit(v_sub(_v(point), self.pos))
         right = self.right()
         self.up = v_unit(v_cross(right, self.sight))

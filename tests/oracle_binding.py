@@ -85,8 +85,7 @@ def camera_pod(cam):
     """cam: the host mirror Camera (pos, sight after look(), builder fields)."""
     c = orc_camera()
     c.frm[:] = cam.pos
-    # the oracle re-runs Camera::new(from, to): any point along sight reproduces the same basis
-    c.to[:] = tuple(p + s for p, s in zip(cam.pos, cam.sight))
+    c.to[:] = cam._to   # the oracle re-runs Camera::new(from, to) itself
     c.focus_dist, c.aperture, c.fov_rad, c.aspect = cam.focus_dist, cam.aperture, cam.fov, cam.aspect
     return c
 

@@ -1,0 +1,321 @@
+"""Parity of the HIP path (through the C ABI of include/cftrt.h) against the CPU oracle, on a real MI355X.
+
+Bars (BASELINE.json north_star):
+  * primary hits: object ids bit-exact; distances and normals within 1e-5 relative
+    (the f64 exact evaluation actually reproduces the oracle's distance bit for bit; both are asserted)
+  * whole loop: same Philox keys on both sides -> per-path radiance agrees except where f32/f64 rounding
+    flips a decision; converged images within 1.5 x the oracle's own seed-to-seed RMSE and 0.5-1 % in mean.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+REL = 1e-5          # north_star tolerance for hit distance / normal
+SEED = 0x5EED0002
+
+
+def _check_hits(world, ow, rays, seed=SEED, pid0=0, level=0, role=0, expect_exact_t=True):
+    ids, t, nrm, pt = world.intersect(rays, seed=seed, pid0=pid0, level=level, role=role)
+    oid, ot, on, op, _ = ow.hit(rays.astype(np.float64), seed=seed, pid0=pid0, level=level, role=role)
+    assert np.array_equal(ids, oid), f"{(ids != oid).sum()} object ids differ"
+    hit = oid >= 0
+    assert np.all(np.isinf(t[~hit]))
+    assert np.all(np.abs(t[hit] - ot[hit]) <= REL * np.abs(ot[hit]))
+    assert np.abs(nrm[hit] - on[hit]).max(initial=0) <= REL
+    assert np.all(np.abs(pt[hit] - op[hit]) <= REL * np.maximum(1.0, np.abs(op[hit])))
+    if expect_exact_t:
+        assert np.array_equal(t[hit], ot[hit]), "f64 exact evaluation no longer bit-identical to the oracle"
+    return hit.sum()
+
+
+# ------------------------------------------------------------------ generate
+@pytest.mark.parametrize("scene", ["scene_rs", "cornell", "s500"])
+@pytest.mark.parametrize("jitter", [False, True])
+def test_generate_matches_emit_rays(rt, orc, scene, jitter):
+    cam = getattr(rt.scenes, {"scene_rs": "scene_rs", "cornell": "cornell_rs", "s500": "s500"}[scene])()[1]
+    W, H = 160, 100
+    n = W * H * 2
+    g = rt.default_device().generate(cam, W, H, 0, n, SEED, jitter)
+    o = orc.emit_rays(cam, W, H, 0, n, SEED, jitter)
+    assert np.abs(g[:, :3] - o[:, :3]).max() <= 2e-6          # origins (|pos| <= 13.5)
+    assert np.abs(g[:, 3:] - o[:, 3:]).max() <= 2e-6          # unit directions
+    assert np.abs(np.linalg.norm(g[:, 3:].astype(np.float64), axis=1) - 1).max() < 3e-7
+    # path ids far beyond 2^32 (C4 has 8.5e9 paths): the 64-bit counter words are used
+    big = (1 << 33) + 12345
+    g2 = rt.default_device().generate(cam, W, H, big, 256, SEED, jitter)
+    o2 = orc.emit_rays(cam, W, H, big, 256, SEED, jitter)
+    assert np.abs(g2 - o2).max() <= 2e-6
+
+
+# ------------------------------------------------------------------ primary hits
+@pytest.mark.parametrize("name", ["scene_rs", "cornell", "s500"])
+def test_primary_hits_golden(rt, orc, name):
+    """GPU against the committed fixtures (tests/golden/make_golden.py): ids bit-exact, t bit-exact."""
+    g = np.load(os.path.join(GOLD, f"primary_{name}.npz"))
+    world = {"scene_rs": lambda: rt.scenes.scene_rs(motion=False), "cornell": rt.scenes.cornell_rs,
+             "s500": rt.scenes.s500}[name]()[0]
+    ids, t, nrm, pt = world.intersect(g["rays"], seed=SEED)
+    assert np.array_equal(ids, g["ids"])
+    hit = g["ids"] >= 0
+    assert np.array_equal(t[hit], g["t"][hit])
+    assert np.abs(nrm[hit] - g["normal"][hit]).max() <= REL
+
+
+@pytest.mark.parametrize("name,W,H", [("s500", 480, 270), ("cornell", 320, 240), ("scene_rs", 400, 250)])
+def test_primary_hits_jittered(rt, orc, name, W, H):
+    world, cam = {"scene_rs": lambda: rt.scenes.scene_rs(motion=False), "cornell": rt.scenes.cornell_rs,
+                  "s500": rt.scenes.s500}[name]()
+    ow = orc.OracleWorld(world)
+    rays = rt.default_device().generate(cam, W, H, 0, W * H, SEED, True)
+    assert _check_hits(world, ow, rays) > 0.5 * W * H
+
+
+def test_hits_with_motion_blur(rt, orc):
+    """Object::moved: a fresh time per object per scan (object.rs:42-55), keyed by (pid, level, role)."""
+    world, cam = rt.scenes.scene_rs(motion=True)
+    ow = orc.OracleWorld(world)
+    W, H = 320, 200
+    rays = rt.default_device().generate(cam, W, H, 0, W * H, SEED, True)
+    for role in (0, 1):
+        _check_hits(world, ow, rays, seed=99, pid0=1000, level=3, role=role)
+    a = world.intersect(rays, seed=99, pid0=1000, level=3, role=0)[1]
+    b = world.intersect(rays, seed=99, pid0=1000, level=3, role=1)[1]
+    assert (a != b).any()          # the two scans of one trace level see different motion times
+
+
+def test_hits_incoherent_rays(rt, orc):
+    """Secondary-ray-like input: origins on and inside the geometry, random directions."""
+    world, _ = rt.scenes.s500()
+    ow = orc.OracleWorld(world)
+    rng = np.random.default_rng(5)
+    n = 200000
+    pos = np.c_[rng.uniform(-12, 12, n), rng.uniform(-12, 12, n), rng.uniform(0.0005, 2.5, n)]
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    rays = np.c_[pos, d].astype(np.float32)
+    assert _check_hits(world, ow, rays) > 0.3 * n
+
+
+def test_hits_s20k(rt, orc):
+    world, cam = rt.scenes.s20k(n_spheres=4000, n_squares=200)
+    ow = orc.OracleWorld(world)
+    W, H = 240, 135
+    rays = rt.default_device().generate(cam, W, H, 0, W * H, SEED, True)
+    _check_hits(world, ow, rays)
+
+
+def test_known_answers(rt):
+    """SURVEY §8c (1),(2) through the C ABI."""
+    w = rt.World.empty()
+    w.add_obj(rt.Object(rt.Sphere((0, 0, 0), 1.0), rt.LambertianModel(1.0)))
+    w.add_obj(rt.Object(rt.Triangle((0, -1, -3), (1, 1, -3), (-1, 1, -3)), rt.LambertianModel(1.0)))
+    rays = np.array([[0, 0, 5, 0, 0, -1], [0, 0, 0, 0, 0, 1], [0, 0, 5, 0, 0, 1], [2, 0, 5, 0, 0, -1],
+                     [0, 0, -2, 0, 0, -1], [3, 0, -2, 0, 0, -1]], np.float32)
+    ids, t, nrm, pt = w.intersect(rays)
+    assert ids.tolist() == [0, 0, -1, -1, 1, -1]
+    assert t[0] == 4.0 and t[1] == 1.0 and t[4] == 1.0
+    assert nrm[0].tolist() == [0, 0, 1] and nrm[1].tolist() == [0, 0, -1] and nrm[4].tolist() == [0, 0, 1]
+    assert pt[0].tolist() == [0, 0, 1]
+
+
+def test_edge_cases(rt, orc):
+    dev = rt.default_device()
+    # empty world + sky: the analytic gradient; empty world without lights: black
+    w = rt.World.empty()
+    w.add_light(rt.SkyLight())
+    cam = rt.Camera.new((0, -5, 1), (0, 0, 1)).with_fov(60.0)
+    rgb, st = w.trace_paths(cam, 16, 8, 0, 128, 5, seed=9)
+    d = dev.generate(cam, 16, 8, 0, 128, 9)[:, 3:6].astype(np.float64)
+    tt = 0.5 * (d[:, 2] + 1.0)
+    want = (1 - tt)[:, None] * np.ones(3) + tt[:, None] * np.array((0.5, 0.7, 1.0))
+    assert np.abs(rgb - want).max() < 1e-6 and int(st.rays) == 128
+    w0 = rt.World.empty()
+    rgb, st = w0.trace_paths(cam, 16, 8, 0, 128, 5, seed=9)
+    assert not rgb.any() and int(st.rays) == 128
+    # zero rays / zero samples / depth 0
+    ids, t, _, _ = w.intersect(np.zeros((0, 6), np.float32))
+    assert len(ids) == 0
+    acc = w.render(cam, 16, 8, 5, spp_begin=3, spp_end=3)
+    assert not acc.any()
+    rgb, st = w.trace_paths(cam, 16, 8, 0, 128, 0, seed=9)
+    assert not rgb.any() and int(st.rays) == 0
+    # depth 1: only the sky is seen, every surface hit runs out of depth (object.rs:327-329)
+    ws, cs = rt.scenes.s500()
+    rgb, st = ws.trace_paths(cs, 64, 36, 0, 64 * 36, 1, seed=9)
+    o, orays = orc.OracleWorld(ws).trace_paths(cs, 64, 36, 0, 64 * 36, 1, 9)
+    assert int(st.rays) == orays == 64 * 36 and np.abs(rgb - o).max() < 1e-6
+    # negative radius (inverted sphere) and a ragged image size
+    wn = rt.World.empty()
+    wn.add_obj(rt.Object(rt.Sphere((0, 0, 0), -3.0), rt.LambertianModel(0.7)))
+    wn.add_obj(rt.Object(rt.Sphere((0, 0, 0), 0.5), rt.Metal(0.1, 0.9)))
+    wn.add_light(rt.LightShape(rt.Sphere((0, 0, 2.5), 0.4)))
+    cn = rt.Camera.new((0, -2, 0), (0, 0, 0)).with_fov(70.0)
+    own = orc.OracleWorld(wn)
+    rays = dev.generate(cn, 37, 23, 0, 37 * 23, 4, True)
+    _check_hits(wn, own, rays)
+    g, st = wn.trace_paths(cn, 37, 23, 0, 37 * 23 * 3, 8, seed=4)
+    o, orays = own.trace_paths(cn, 37, 23, 0, 37 * 23 * 3, 8, 4)
+    assert (np.abs(g - o).max(axis=1) > 1e-3).mean() < 0.02
+    assert abs(g.mean() - o.mean()) < 0.02 * o.mean() + 1e-3
+
+
+def test_error_codes(rt):
+    L = rt.load()
+    dev = rt.default_device()
+    h = C.c_void_p()
+    assert L.cftrt_scene_create(dev.h, C.byref(h)) == 0
+    cam = rt.Camera.new((0, -5, 1), (0, 0, 1))._pod()
+    buf = np.zeros(4 * 4 * 3, np.float32)
+    fp = buf.ctypes.data_as(C.POINTER(C.c_float))
+    assert L.cftrt_render(h, C.byref(cam), 4, 4, 0, 1, 5, 0, fp, None) == 3          # not committed
+    assert b"not committed" in L.cftrt_last_error(dev.h)
+    bad = np.array([-1], np.int32).ctypes.data_as(C.POINTER(C.c_int32))
+    one = np.ones(3).ctypes.data_as(C.POINTER(C.c_double))
+    assert L.cftrt_scene_set_spheres(h, one, one, None, bad, bad, 1) == 1               # negative ids
+    assert L.cftrt_scene_set_spheres(h, None, one, None, bad, bad, 1) == 1              # null pointer
+    assert L.cftrt_scene_commit(h) == 0
+    assert L.cftrt_scene_commit(h) == 3                                                 # twice
+    assert L.cftrt_scene_set_materials(h, None, 0) == 3                                 # after commit
+    assert L.cftrt_render(h, C.byref(cam), 0, 4, 0, 1, 5, 0, fp, None) == 1             # zero width
+    assert L.cftrt_render(h, C.byref(cam), 4, 4, 2, 1, 5, 0, fp, None) == 1             # spp_end < spp_begin
+    assert L.cftrt_render(h, C.byref(cam), 4, 4, 0, 1, 257, 0, fp, None) == 4           # depth limit
+    assert L.cftrt_render(h, C.byref(cam), 4, 4, 0, 1, 5, 0, None, None) == 1           # null output
+    assert L.cftrt_render(h, C.byref(cam), 4, 4, 0, 1, 5, 0, fp, None) == 0
+    L.cftrt_scene_destroy(h)
+    bad_ctx = C.c_void_p()
+    assert L.cftrt_ctx_create(9999, C.byref(bad_ctx)) == 1 and not bad_ctx.value
+    assert b"out of range" in L.cftrt_last_error(None)
+
+
+# ------------------------------------------------------------------ whole loop, same Philox keys
+@pytest.mark.parametrize("name,W,H,spp,depth", [("s500", 96, 54, 4, 50), ("cornell", 80, 60, 4, 10),
+                                                ("scene_rs", 80, 50, 4, 10)])
+def test_per_path_radiance(rt, orc, name, W, H, spp, depth):
+    world, cam = {"scene_rs": rt.scenes.scene_rs, "cornell": rt.scenes.cornell_rs, "s500": rt.scenes.s500}[name]()
+    n = W * H * spp
+    g, st = world.trace_paths(cam, W, H, 0, n, depth, seed=11)
+    o, orays = orc.OracleWorld(world).trace_paths(cam, W, H, 0, n, depth, 11)
+    differing = (np.abs(g - o).max(axis=1) > 1e-3).mean()
+    assert differing < 0.005, f"{differing:.4f} of the paths differ"
+    assert abs(int(st.rays) - orays) <= 0.002 * orays
+    assert np.abs(g.mean(0) - o.mean(0)).max() < 0.005 * o.mean()
+
+
+def test_phong_point_parallel_lights(rt, orc):
+    """The shadow kernel: PhongModel::render with every light type (basic.rs:57-94, light.rs)."""
+    w = rt.World.empty()
+    w.add_obj(rt.Object(rt.Cube((0, 0, 0), (1, 0, 0), (0, 1, 0), 4.0),
+                        rt.PhongModel().with_shininess(4.0).with_diffuse(0.8).with_color((0.9, 0.8, 0.7))))
+    w.add_obj(rt.Object(rt.Sphere((-0.3, 0.6, -1.4), 0.6), rt.PhongModel().with_shininess(2.5).with_color((0.2, 0.5, 0.9))))
+    w.add_obj(rt.Object(rt.Sphere((0.7, -0.2, -1.5), 0.5), rt.Metal(0.05, 0.9)))
+    w.add_light(rt.PointLight((0.0, 0.0, 1.5)).with_color((1.0, 0.9, 0.8)))
+    w.add_light(rt.ParallelLight((0.3, 0.2, -1.0)).with_color((0.2, 0.3, 0.4)))
+    w.add_light(rt.LightShape(rt.Square((0.0, 0.0, 1.99), (1.0, 0.0, 0.0), (0.0, -1.0, 0.0), 1.0)))
+    w.add_light(rt.SkyLight())
+    cam = rt.Camera.new((1.6, -1.2, 0.2), (0, 0, -1.0)).with_fov(75.0)
+    W, H, spp = 96, 64, 2
+    n = W * H * spp
+    g, st = w.trace_paths(cam, W, H, 0, n, 6, seed=21)
+    o, orays = orc.OracleWorld(w).trace_paths(cam, W, H, 0, n, 6, 21)
+    assert int(st.phong_rays) > 0
+    differing = (np.abs(g - o).max(axis=1) > 2e-3 * np.maximum(1.0, o.max(axis=1))).mean()
+    assert differing < 0.01, f"{differing:.4f} of the paths differ"
+    assert abs(int(st.rays) - orays) <= 0.005 * orays
+    assert np.abs(g.mean(0) - o.mean(0)).max() < 0.01 * o.mean()
+
+
+def test_cornell_point_light_variant(rt, orc):
+    w, cam = rt.scenes.cornell_rs(point_light=True)
+    W, H = 100, 75
+    g, st = w.trace_paths(cam, W, H, 0, W * H, 10, seed=3)
+    o, orays = orc.OracleWorld(w).trace_paths(cam, W, H, 0, W * H, 10, 3)
+    assert (np.abs(g - o).max(axis=1) > 2e-3 * np.maximum(1.0, o.max(axis=1))).mean() < 0.01
+    assert int(st.rays) == orays
+
+
+# ------------------------------------------------------------------ converged images (different seeds)
+def _rmse(a, b):
+    return float(np.sqrt(np.mean((a - b) ** 2)))
+
+
+@pytest.mark.parametrize("name,W,H,spp,depth", [("scene_rs", 160, 100, 64, 10), ("cornell", 120, 90, 128, 10)])
+def test_converged_image_rmse(rt, orc, name, W, H, spp, depth):
+    """RMSE(GPU, oracle) <= 1.5 x RMSE(oracle seed A, oracle seed B) on the linear image, and the mean image
+    brightness within 1 % (SURVEY §8c tolerance).  scene_rs runs with motion blur ON."""
+    world, cam = {"scene_rs": rt.scenes.scene_rs, "cornell": rt.scenes.cornell_rs}[name]()
+    cam = cam.with_sample_rate(spp)
+    ow = orc.OracleWorld(world)
+    a, _ = ow.render(cam, W, H, depth, 101, nthreads=16)
+    b, _ = ow.render(cam, W, H, depth, 202, nthreads=16)
+    g = world.render(cam, W, H, depth, seed=303).astype(np.float64)
+    a, b, g = a / spp, b / spp, g / spp
+    self_rmse = _rmse(a, b)
+    assert _rmse(g, a) <= 1.5 * self_rmse and _rmse(g, b) <= 1.5 * self_rmse
+    ref = 0.5 * (a.mean() + b.mean())
+    assert abs(g.mean() - ref) <= 0.01 * ref
+    psnr = 10 * np.log10(1.0 / max(_rmse(g, 0.5 * (a + b)) ** 2, 1e-12))
+    print(f"{name}: rmse_self {self_rmse:.4f} rmse_gpu {_rmse(g, a):.4f} psnr vs oracle mean {psnr:.1f} dB")
+    # the 8-bit resolve (scene.rs:122-127) on the device agrees with the oracle's on the same accumulation
+    acc32 = (g * spp).astype(np.float32)
+    assert np.abs(rt.vec3_to_rgb(acc32, spp).astype(int) - orc.to_rgb8(acc32.astype(np.float64), spp).astype(int)).max() <= 1
+
+
+def test_golden_image_statistics(rt):
+    """GPU render against the committed oracle images (different Philox seed): mean within 2 %."""
+    for name, fn, W, H in [("cornell", rt.scenes.cornell_rs, 40, 30), ("s500", rt.scenes.s500, 48, 27)]:
+        gold = np.load(os.path.join(GOLD, f"image_{name}.npz"))
+        world, cam = fn()
+        spp, depth = int(gold["spp"]), int(gold["depth"])
+        acc, st = world.render(cam.with_sample_rate(4 * spp), W, H, depth, seed=1, return_stats=True)
+        assert abs(acc.mean() / (4 * spp) - gold["accum"].mean() / spp) < 0.02 * gold["accum"].mean() / spp
+        # same seed: the very same image up to decision flips
+        same = world.render(cam.with_sample_rate(spp), W, H, depth, seed=SEED)
+        close = np.abs(same - gold["accum"]) <= 1e-3 * np.maximum(1.0, gold["accum"])
+        assert close.mean() > 0.99
+
+
+# ------------------------------------------------------------------ properties at size
+def test_determinism_and_sample_range_linearity(rt):
+    world, cam = rt.scenes.s500()
+    W, H = 640, 360
+    a = world.render(cam, W, H, 50, spp_begin=0, spp_end=8)
+    b = world.render(cam, W, H, 50, spp_begin=0, spp_end=8)
+    assert np.array_equal(a, b)                                   # no atomics on pixels: bit-reproducible
+    lo = world.render(cam, W, H, 50, spp_begin=0, spp_end=5)
+    hi = world.render(cam, W, H, 50, spp_begin=5, spp_end=8)
+    assert np.allclose(lo + hi, a, rtol=1e-5, atol=1e-5)          # any split of the sample range sums to the whole
+    # a tiny workspace forces many passes: same image
+    dev = rt.default_device()
+    dev.set_workspace_limit(64 << 20)
+    try:
+        c, st = world.render(cam, W, H, 50, spp_begin=0, spp_end=8, return_stats=True)
+    finally:
+        dev.set_workspace_limit(40 << 30)
+    assert int(st.passes) > 1 and np.allclose(c, a, rtol=1e-5, atol=1e-5)
+
+
+def test_full_size_properties(rt, orc):
+    """BASELINE.json configs[2] at full size (1920x1080, 64 spp, depth 50): size-independent properties."""
+    world, cam = rt.scenes.s500()
+    W, H, spp = 1920, 1080, 64
+    acc, st = world.render(cam, W, H, 50, return_stats=True)
+    lv = list(st.rays_per_level[: int(st.levels)])
+    assert lv[0] == W * H * spp == int(st.paths)
+    assert all(lv[i] >= lv[i + 1] for i in range(len(lv) - 1))          # a path never forks (scatter <= 1 ray)
+    assert sum(lv) == int(st.rays)
+    assert np.isfinite(acc).all() and acc.min() >= 0.0
+    assert acc.max() <= spp * 1.0 + 1e-3                                # every k <= 1 and the sky <= 1
+    # the full-size image, box-filtered 20x, against a low-resolution oracle render of the same camera
+    small = acc.reshape(54, 20, 96, 20, 3).mean(axis=(1, 3)) / spp
+    o, _ = orc.OracleWorld(world).render(cam.with_sample_rate(32), 96, 54, 50, 7, nthreads=16)
+    o = o / 32
+    assert abs(small.mean() - o.mean()) < 0.01 * o.mean()
+    assert np.sqrt(np.mean((small - o) ** 2)) < 0.05
+    # linearity: two halves of the sample range add up to the frame
+    lo = world.render(cam, W, H, 50, spp_begin=0, spp_end=32)
+    hi = world.render(cam, W, H, 50, spp_begin=32, spp_end=64)
+    assert np.allclose(lo + hi, acc, rtol=1e-5, atol=1e-4)
