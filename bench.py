@@ -80,6 +80,8 @@ def main():
     W, H, spp = args.width, args.height, args.spp
     scene, cam = rt.scenes.s500(width=W, height=H, spp=spp)
     dev = rt.Device(local_rank)
+    if os.environ.get("CFTRT_VARIANT"):
+        dev.set_variant(int(os.environ["CFTRT_VARIANT"]))
     scene.commit(dev)
     accum = torch.zeros(H * W * 3, dtype=torch.float32, device=f"cuda:{local_rank}")
     spp_begin, spp_end = rank * spp, (rank + 1) * spp
@@ -138,7 +140,8 @@ def main():
                                    f"max depth {DEPTH} (BASELINE.json configs[2]); sample-range split over GPUs, "
                                    "RCCL reduce of the f32 image",
                        "rays_per_step_per_gpu": int(s0.rays), "paths_per_step_per_gpu": int(s0.paths),
-                       "trace_levels": int(s0.levels)},
+                       "trace_levels": int(s0.levels), "exact_second_evals": int(s0.exact_second),
+                       "exact_rescans": int(s0.exact_rescan)},
             "roofline": {"bound": "valu_fp32", "kernel": "k_intersect", "achieved": achieved,
                          "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
                          "traffic": None,

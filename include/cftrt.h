@@ -116,7 +116,7 @@ void cftrt_ctx_destroy(cftrt_ctx* ctx);
 const char* cftrt_last_error(const cftrt_ctx* ctx);
 /* Cap on the path workspace (bytes of HBM the render calls may hold; default 40 GiB). */
 int cftrt_ctx_set_workspace_limit(cftrt_ctx* ctx, uint64_t bytes);
-/* Intersect-kernel variant: 0 = primitives via scalar (SGPR) loads, 1 = LDS-staged tiles. */
+/* Intersect-kernel variant: rays per lane of k_intersect (1..4); 0 = the tuned default. */
 int cftrt_ctx_set_variant(cftrt_ctx* ctx, int variant);
 
 /* ---- scene (replaces World::empty/add_obj/add_light, src/object.rs:311-324) ------------- */

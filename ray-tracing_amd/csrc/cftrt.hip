@@ -162,7 +162,7 @@ int cftrt_ctx_set_workspace_limit(cftrt_ctx* ctx, uint64_t bytes) {
 
 int cftrt_ctx_set_variant(cftrt_ctx* ctx, int variant) {
   if (!ctx) return CFTRT_ERR_INVALID;
-  if (variant < 0 || variant > 1) return fail(ctx, CFTRT_ERR_INVALID, "unknown intersect variant");
+  if (variant < 0 || variant > 4) return fail(ctx, CFTRT_ERR_INVALID, "unknown intersect variant");
   ctx->variant = variant;
   return CFTRT_OK;
 }
@@ -336,8 +336,8 @@ int cftrt_scene_commit(cftrt_scene* s) {
     }
   }
   const int n_sphF_real = (int)sphF_gid.size();
-  while (sphF.size() % 4) sphF.push_back(make_float4(0.f, 0.f, 0.f, -1.f));   // never hit: disc = -1 - |l|^2
-  for (int k = 0; k < 4; ++k) sphF.push_back(make_float4(0.f, 0.f, 0.f, -1.f));   // the prefetched extra batch
+  while (sphF.size() % 4) sphF.push_back(make_float4(0.f, 0.f, 0.f, -1e30f));   // never hit: disc = -1e30 - |l|^2
+  for (int k = 0; k < 4; ++k) sphF.push_back(make_float4(0.f, 0.f, 0.f, -1e30f));   // the prefetched extra batch
   std::vector<MatDev> mats(nm);
   int n_phong = 0;
   for (int i = 0; i < nm; ++i) {
@@ -386,6 +386,52 @@ int cftrt_scene_commit(cftrt_scene* s) {
   D.n_lights = (int)lights.size();
   D.any_motion = any_motion;
   D.n_phong_mats = n_phong;
+  {
+    // f32 error model of the cull.  eps = 2^-24 (unit roundoff); every constant carries
+    // a factor >= 2 over the bound derived there.
+    const double eps = 5.9604644775390625e-8;
+    double rmax = 0., cmax = 0., bc[3] = {0., 0., 0.};
+    int nf = 0;
+    for (int i = 0; i < ns; ++i) {
+      if (std::fabs(s->sph_r[i]) >= s->precise_radius) continue;
+      const double* c = &s->sph_c[3 * i];
+      const double* mv = &s->sph_mv[3 * i];
+      rmax = std::max(rmax, std::fabs(s->sph_r[i]));
+      cmax = std::max(cmax, std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) + std::sqrt(mv[0] * mv[0] + mv[1] * mv[1] + mv[2] * mv[2]));
+      bc[0] += c[0]; bc[1] += c[1]; bc[2] += c[2];
+      ++nf;
+    }
+    if (nf) { bc[0] /= nf; bc[1] /= nf; bc[2] /= nf; }
+    double brad = 0.;
+    for (int i = 0; i < ns; ++i) {
+      if (std::fabs(s->sph_r[i]) >= s->precise_radius) continue;
+      const double* c = &s->sph_c[3 * i];
+      const double* mv = &s->sph_mv[3 * i];
+      double dx = c[0] - bc[0], dy = c[1] - bc[1], dz = c[2] - bc[2];
+      brad = std::max(brad, std::sqrt(dx * dx + dy * dy + dz * dz) + std::sqrt(mv[0] * mv[0] + mv[1] * mv[1] + mv[2] * mv[2]));
+    }
+    D.K1 = (float)(32. * eps * rmax);
+    D.K2 = (float)(eps * rmax * (48. * rmax + 16. * cmax));
+    D.K3 = (float)(8. * eps);
+    D.K4 = (float)(eps * (16. * rmax + 4. * cmax));
+    D.bcx = (float)bc[0]; D.bcy = (float)bc[1]; D.bcz = (float)bc[2];
+    D.brad = (float)(brad * 1.000001 + 1e-6);
+    double emax = 0., pmax = 0.;
+    for (int i = 0; i < nt; ++i) {
+      const double* p = &s->tri_p[9 * i];
+      const double* mv = &s->tri_mv[3 * i];
+      double e1 = std::sqrt((p[3] - p[0]) * (p[3] - p[0]) + (p[4] - p[1]) * (p[4] - p[1]) + (p[5] - p[2]) * (p[5] - p[2]));
+      double e2 = std::sqrt((p[6] - p[0]) * (p[6] - p[0]) + (p[7] - p[1]) * (p[7] - p[1]) + (p[8] - p[2]) * (p[8] - p[2]));
+      emax = std::max(emax, std::max(e1, e2));
+      pmax = std::max(pmax, std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) + std::sqrt(mv[0] * mv[0] + mv[1] * mv[1] + mv[2] * mv[2]));
+    }
+    D.tKA = (float)(32. * eps * emax * emax);
+    D.tKU1 = (float)(32. * eps * emax);
+    D.tKU2 = (float)(32. * eps * emax * (pmax + emax));
+    D.tKT1 = (float)(32. * eps * emax * emax);
+    D.tKT2 = (float)(32. * eps * emax * emax * (pmax + emax));
+    D.tKT3 = (float)(32. * eps * emax * emax);
+  }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   s->committed = true;
   return CFTRT_OK;
@@ -437,6 +483,22 @@ static uint32_t grid_for(cftrt_ctx* ctx, uint64_t n, uint32_t per_cu) {
   if (blocks > cap) blocks = cap;
   if (blocks == 0) blocks = 1;
   return (uint32_t)blocks;
+}
+
+
+// k_intersect<R>: R rays per lane.  ctx->variant picks R (0 = default).
+static void launch_intersect(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, const uint32_t* counts, uint32_t level,
+                             uint64_t pid_base, uint32_t k0, uint32_t k1, uint32_t role, HitDev out, uint32_t* xstats,
+                             uint32_t P) {
+  const int R = ctx->variant ? ctx->variant : CFT_RAYS_PER_LANE;
+  const uint32_t g = grid_for(ctx, ((uint64_t)P + R - 1) / R, 8);
+  hipStream_t st = ctx->stream;
+  switch (R) {
+    case 1: hipLaunchKernelGGL((k_intersect<1>), dim3(g), dim3(CFT_BLOCK), 0, st, S, q, counts, level, pid_base, k0, k1, role, out, xstats); break;
+    case 3: hipLaunchKernelGGL((k_intersect<3>), dim3(g), dim3(CFT_BLOCK), 0, st, S, q, counts, level, pid_base, k0, k1, role, out, xstats); break;
+    case 4: hipLaunchKernelGGL((k_intersect<4>), dim3(g), dim3(CFT_BLOCK), 0, st, S, q, counts, level, pid_base, k0, k1, role, out, xstats); break;
+    default: hipLaunchKernelGGL((k_intersect<2>), dim3(g), dim3(CFT_BLOCK), 0, st, S, q, counts, level, pid_base, k0, k1, role, out, xstats); break;
+  }
 }
 
 struct EvTimer {   // pairs of events around launches on the ctx stream, summed per class after a sync
@@ -500,7 +562,7 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
   if ((rc = ensure(ctx, ctx->counts, ncount * 4))) return rc;
   uint32_t* counts = (uint32_t*)ctx->counts.p;
   uint32_t* phong_counts = counts + CFTRT_MAX_LEVELS + 1;
-  uint32_t* rescans = counts + 2 * CFTRT_MAX_LEVELS + 2;
+  uint32_t* xstats = counts + 2 * CFTRT_MAX_LEVELS + 2;   // [0] second exact evaluations, [1] f64 rescans
   hipStream_t st_ = ctx->stream;
   HIP_TRY(ctx, hipMemsetAsync(counts, 0, ncount * 4, st_));
   HIP_TRY(ctx, hipMemcpyAsync(counts, &P, 4, hipMemcpyHostToDevice, st_));
@@ -522,11 +584,8 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
     int in = level & 1, outq = in ^ 1;
     const uint32_t nl = (uint32_t)S.n_lights;
     tm.begin(CLS_ISECT);
-    if (two_scans)
-      hipLaunchKernelGGL(k_intersect, dim3(grid), dim3(CFT_BLOCK), 0, st_, S, q[in], counts, level, pid_base, k0, k1,
-                         0u, hA, rescans);
-    hipLaunchKernelGGL(k_intersect, dim3(grid), dim3(CFT_BLOCK), 0, st_, S, q[in], counts, level, pid_base, k0, k1, nl,
-                       hB, rescans);
+    if (two_scans) launch_intersect(ctx, S, q[in], counts, level, pid_base, k0, k1, 0u, hA, xstats, P);
+    launch_intersect(ctx, S, q[in], counts, level, pid_base, k0, k1, nl, hB, xstats, P);
     tm.end();
     tm.begin(CLS_SHADE);
     hipLaunchKernelGGL(k_shade, dim3(grid), dim3(CFT_BLOCK), 0, st_, S, q[in], hA, hB, counts, level, max_depth, pid_base,
@@ -535,7 +594,7 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
     if (phong) {
       tm.begin(CLS_SHADOW);
       hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(CFT_BLOCK), 0, st_, S, pq, phong_counts, level, pid_base, k0, k1, rad,
-                         rescans);
+                         xstats);
       tm.end();
     }
     levels_run = level + 1;
@@ -565,7 +624,8 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
       st->rays += pr;
       if (hc[l] && l + 1 > st->levels) st->levels = l + 1;
     }
-    st->exact_rescan += hc[2 * CFTRT_MAX_LEVELS + 2];
+    st->exact_second += hc[2 * CFTRT_MAX_LEVELS + 2];
+    st->exact_rescan += hc[2 * CFTRT_MAX_LEVELS + 3];
     st->paths += P;
     st->passes += 1;
   }

@@ -19,6 +19,9 @@
 
 #define CFT_BLOCK 256
 #define CFT_SHADE_CHUNK 1024
+#ifndef CFT_RAYS_PER_LANE
+#define CFT_RAYS_PER_LANE 2
+#endif
 
 // constant-address-space views: a wave-uniform index then compiles to s_load (SGPR operands)
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -155,44 +158,71 @@ __device__ __forceinline__ d3 exact_normal(const SceneDev& S, int g, d3 p, uint3
 }
 
 // ------------------------------------------------------------------ f32 cull (hot loops)
-// One sphere against one ray.  13 VALU instructions on the common (miss) path:
-// 3 sub, 3 dot, 3 fma (l = oc - b d), 3 fma (disc = r^2 - l.l), 1 compare.
-__device__ __forceinline__ void cull_sphere(float ox, float oy, float oz, float dx, float dy, float dz,
-                                            float cx, float cy, float cz, float r2, int idx,
-                                            float& best_t, int& best_i) {
-  float ocx = ox - cx, ocy = oy - cy, ocz = oz - cz;
-  float b = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
-  float lx = fmaf(-b, dx, ocx), ly = fmaf(-b, dy, ocy), lz = fmaf(-b, dz, ocz);
-  float disc = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, r2)));
-  if (disc >= 0.0f) {
-    float sq = __builtin_amdgcn_sqrtf(disc);
-    float t1 = -b - sq, t2 = sq - b;
-    float t = t1 < 0.0f ? t2 : t1;
-    if (t2 >= 0.0f && t < best_t) {
-      best_t = t;
-      best_i = idx;
-    }
+// The scan keeps, per ray, the three smallest LOWER BOUNDS on the hit distance among all primitives
+// the f32 arithmetic cannot rule out.  After the scan the best two are evaluated exactly (f64,
+// reference formula); if the third bound could still win, the ray is rescanned entirely in f64.
+// With conservative bounds this returns exactly the primitive and distance the f64 reference finds:
+// the true winner w has t_w >= lo_w; if w is not among the two smallest bounds then lo3 <= lo_w <= t_w
+// <= (any exact hit found) and the rescan fires.
+struct Cand {
+  float lo1, lo2, lo3;   // three smallest lower bounds, ascending (+inf when absent)
+  int i1, i2;            // list indices of the first two (-1 when absent)
+};
+__device__ __forceinline__ void cand_init(Cand& c) {
+  c.lo1 = c.lo2 = c.lo3 = __builtin_inff();
+  c.i1 = c.i2 = -1;
+}
+__device__ __forceinline__ void cand_insert(Cand& c, float tlo, int idx) {
+  const bool c1 = tlo < c.lo1, c2 = tlo < c.lo2;
+  c.lo3 = __builtin_amdgcn_fmed3f(c.lo2, c.lo3, tlo);
+  c.i2 = c1 ? c.i1 : (c2 ? idx : c.i2);
+  c.lo2 = __builtin_amdgcn_fmed3f(c.lo1, c.lo2, tlo);
+  c.i1 = c1 ? idx : c.i1;
+  c.lo1 = fminf(c.lo1, tlo);
+}
+
+#define CFT_U4EPS 2.3841858e-7f   // 4 * 2^-24: slack for a 1-ulp sqrt/rcp and the final adds
+
+// A sphere the fast path could not rule out (disc >= -E_ray): turn (q, disc) into a lower bound.
+//   q = oc.d,  disc = r^2 - |oc - q d|^2  (both f32, error model in DESIGN.md §4)
+__device__ __forceinline__ void sphere_candidate(const SceneDev& S, float q, float d, int idx, float U, Cand& c) {
+  const float aq = fabsf(q);
+  const float e = fmaf(aq, S.K1, S.K2);                 // |disc - true disc| <= e
+  const float eq = fmaf(aq, S.K3, S.K4);                // |q - true q| <= eq
+  const bool inside = fmaf(-q, q, d) > e;               // r^2 - |oc|^2 = disc - q^2 certainly > 0
+  const float arg = inside ? fmaxf(d - e, 0.0f) : d + e;
+  if (arg >= 0.0f) {
+    const float s = __builtin_amdgcn_sqrtf(arg);
+    const float s_hi = fmaf(s, CFT_U4EPS, s), s_lo = fmaf(-s, CFT_U4EPS, s);
+    // outside: t = t1 = -q - sqrt(disc) >= -q - s_hi ; inside: t = t2 = -q + sqrt(disc) >= -q + s_lo
+    float tlo = inside ? (s_lo - q) : -(q + s_hi);
+    tlo = tlo - eq - fabsf(tlo) * CFT_U4EPS;
+    const bool possible = inside || (s_hi - q + eq >= 0.0f);   // t2 could be >= 0
+    tlo = fmaxf(tlo, 0.0f);
+    if (possible && tlo <= U) cand_insert(c, tlo, idx);
   }
 }
 
-// One triangle (p0, e1, e2) against one ray: Moller-Trumbore with slack so that borderline cases
-// reach the exact evaluation.
-__device__ __forceinline__ void cull_tri(float ox, float oy, float oz, float dx, float dy, float dz, f3 p0,
-                                         f3 e1, f3 e2, int idx, float& best_t, int& best_i) {
-  const float SLACK = 1e-4f;
+// Moller-Trumbore in f32 with explicit error margins (triangle = p0, e1, e2).
+__device__ __forceinline__ void tri_candidate(const SceneDev& S, float ox, float oy, float oz, float dx, float dy,
+                                              float dz, f3 p0, f3 e1, f3 e2, int idx, float U, Cand& c) {
   f3 d = mk3(dx, dy, dz);
   f3 h = cross3(d, e2);
   float a = dot3(e1, h);
-  if (fabsf(a) > CFT_EPS * 0.99f) {
+  if (fabsf(a) >= CFT_EPS - S.tKA) {                    // the reference rejects |a| < EPS (object.rs:105)
     float f = __builtin_amdgcn_rcpf(a);
+    float af = fabsf(f);
     f3 s = mk3(ox - p0.x, oy - p0.y, oz - p0.z);
+    float s1 = fabsf(s.x) + fabsf(s.y) + fabsf(s.z);    // >= |s|
     float u = f * dot3(s, h);
     f3 q = cross3(s, e1);
     float v = f * dot3(d, q);
     float t = f * dot3(e2, q);
-    if (u >= -SLACK && v >= -SLACK && u + v <= 1.0f + SLACK && t > CFT_EPS * 0.99f && t < best_t) {
-      best_t = t;
-      best_i = idx;
+    float mu = af * fmaf(s1, S.tKU1, S.tKU2);           // |u - true u|, |v - true v| <= mu
+    float mt = af * fmaf(fabsf(t), S.tKT3, fmaf(s1, S.tKT1, S.tKT2));   // |t - true t| <= mt
+    if (u >= -mu && v >= -mu && u <= 1.0f + mu && u + v <= 1.0f + 2.0f * mu && t + mt > CFT_EPS) {
+      float tlo = fmaxf(t - mt, 0.0f);
+      if (tlo <= U) cand_insert(c, tlo, idx);
     }
   }
 }
@@ -202,63 +232,91 @@ struct Closest {
   int g;      // global prim id, -1 on miss
 };
 
-// Ray::hit for one ray.  scan_word keys the per-object motion times of this scan.
-// Counters: cnt[0] += rays that needed the f64 rescan.
-__device__ __forceinline__ Closest closest_hit(const SceneDev& S, float ox, float oy, float oz, float dx,
-                                               float dy, float dz, uint32_t scan_word, uint32_t* rescans) {
-  d3 o = d3{(double)ox, (double)oy, (double)oz};
-  d3 d = d3{(double)dx, (double)dy, (double)dz};
-  // 1. precise spheres: exact for every ray
-  double Tp = __builtin_inf();
-  int gp = -1;
-  for (int k = 0; k < S.n_prec; ++k) {
-    int g = AS_CONST(c_i32p, S.prec_gid)[k];
-    double t;
-    if (exact_prim(S, g, o, d, scan_word, &t)) {
-      if (t < Tp || (t == Tp && S.prim_obj[g] < S.prim_obj[gp])) { Tp = t; gp = g; }
-    }
+// R rays per lane: the wave-uniform sphere operands (SGPRs) are fetched once for R tests, and one
+// uniform branch per sphere serves all of them.
+template <int R>
+struct RayPack {
+  float ox[R], oy[R], oz[R], dx[R], dy[R], dz[R];
+  float negE[R];      // -(fast-path margin) of the ray: candidates have disc >= negE
+  float U[R];         // upper bound on the winner's distance (exact precise-sphere hit), f32 rounded up
+  uint32_t word[R];   // motion key of this scan
+  Cand c[R];
+};
+
+template <int R>
+__device__ __forceinline__ void scan_sphere(const SceneDev& S, RayPack<R>& P, float negEmin, float cx, float cy,
+                                            float cz, float r2, int idx) {
+  float q[R], d[R];
+  float m = -__builtin_inff();
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float ocx = P.ox[r] - cx, ocy = P.oy[r] - cy, ocz = P.oz[r] - cz;
+    q[r] = fmaf(ocz, P.dz[r], fmaf(ocy, P.dy[r], ocx * P.dx[r]));
+    float lx = fmaf(-q[r], P.dx[r], ocx), ly = fmaf(-q[r], P.dy[r], ocy), lz = fmaf(-q[r], P.dz[r], ocz);
+    d[r] = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, r2)));
+    m = fmaxf(m, d[r]);
   }
-  // 2. f32 cull over everything else; anything not clearly behind the precise hit stays a candidate
-  float best_t = (gp >= 0) ? (float)Tp * (1.0f + 1e-5f) + 1e-5f : __builtin_inff();
-  int best_i = -1;   // index into the concatenation [sphF | msph | triF | mtri]
+  if (__ballot(m >= negEmin) != 0ull) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (d[r] >= P.negE[r]) sphere_candidate(S, q[r], d[r], idx, P.U[r], P.c[r]);
+  }
+}
+
+// f32 scan of every non-precise primitive for R rays (indices into [sphF | msph | triF | mtri]).
+template <int R>
+__device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R>& P) {
+  float negEmin = P.negE[0];
+#pragma unroll
+  for (int r = 1; r < R; ++r) negEmin = fminf(negEmin, P.negE[r]);
   {
     // 4 spheres per s_load_dwordx16, fetched one batch ahead; the array is padded on the host with
-    // never-hit spheres (r^2 = -1) to a multiple of 4 plus one extra batch.
+    // never-hit spheres (r^2 = -1e30) to a multiple of 4 plus one extra batch.
     c_f16p sp = AS_CONST(c_f16p, S.sphF);
     const int n4 = (S.n_sphF + 3) >> 2;
     v16f cur = sp[0];
     for (int s4 = 0; s4 < n4; ++s4) {
       v16f nxt = sp[s4 + 1];
       const int s = s4 << 2;
-      cull_sphere(ox, oy, oz, dx, dy, dz, cur[0], cur[1], cur[2], cur[3], s, best_t, best_i);
-      cull_sphere(ox, oy, oz, dx, dy, dz, cur[4], cur[5], cur[6], cur[7], s + 1, best_t, best_i);
-      cull_sphere(ox, oy, oz, dx, dy, dz, cur[8], cur[9], cur[10], cur[11], s + 2, best_t, best_i);
-      cull_sphere(ox, oy, oz, dx, dy, dz, cur[12], cur[13], cur[14], cur[15], s + 3, best_t, best_i);
+      scan_sphere<R>(S, P, negEmin, cur[0], cur[1], cur[2], cur[3], s);
+      scan_sphere<R>(S, P, negEmin, cur[4], cur[5], cur[6], cur[7], s + 1);
+      scan_sphere<R>(S, P, negEmin, cur[8], cur[9], cur[10], cur[11], s + 2);
+      scan_sphere<R>(S, P, negEmin, cur[12], cur[13], cur[14], cur[15], s + 3);
       cur = nxt;
     }
   }
   int base = S.n_sphF;
-  if (S.n_msph) {
+  if (S.n_msph) {   // moving spheres: centre + time * moving_to, one time per object per scan (object.rs:42-55)
     c_f4p sp = AS_CONST(c_f4p, S.msphF);
     c_f4p mv = AS_CONST(c_f4p, S.msphMv);
     c_i32p gid = AS_CONST(c_i32p, S.msph_gid);
     c_i32p pobj = AS_CONST(c_i32p, S.prim_obj);
     for (int s = 0; s < S.n_msph; ++s) {
-      v4f c = sp[s];
+      v4f cc = sp[s];
       v4f m = mv[s];
-      float tm = motion_time(scan_word, (uint32_t)pobj[gid[s]]);
-      cull_sphere(ox, oy, oz, dx, dy, dz, fmaf(m.x, tm, c.x), fmaf(m.y, tm, c.y), fmaf(m.z, tm, c.z), c.w,
-                  base + s, best_t, best_i);
+      uint32_t obj = (uint32_t)pobj[gid[s]];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float tm = motion_time(P.word[r], obj);
+        float cx = fmaf(m.x, tm, cc.x), cy = fmaf(m.y, tm, cc.y), cz = fmaf(m.z, tm, cc.z);
+        float ocx = P.ox[r] - cx, ocy = P.oy[r] - cy, ocz = P.oz[r] - cz;
+        float q = fmaf(ocz, P.dz[r], fmaf(ocy, P.dy[r], ocx * P.dx[r]));
+        float lx = fmaf(-q, P.dx[r], ocx), ly = fmaf(-q, P.dy[r], ocy), lz = fmaf(-q, P.dz[r], ocz);
+        float d = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, cc.w)));
+        if (d >= P.negE[r]) sphere_candidate(S, q, d, base + s, P.U[r], P.c[r]);
+      }
     }
   }
   base += S.n_msph;
   {
     c_f4p tp = AS_CONST(c_f4p, S.triF);
-    int n = S.n_triF;
+    const int n = S.n_triF;
     for (int s = 0; s < n; ++s) {
-      v4f a = tp[3 * s], b = tp[3 * s + 1], c = tp[3 * s + 2];
-      cull_tri(ox, oy, oz, dx, dy, dz, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), base + s,
-               best_t, best_i);
+      v4f a = tp[3 * s], b = tp[3 * s + 1], cc = tp[3 * s + 2];
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        tri_candidate(S, P.ox[r], P.oy[r], P.oz[r], P.dx[r], P.dy[r], P.dz[r], mk3(a.x, a.y, a.z),
+                      mk3(b.x, b.y, b.z), mk3(cc.x, cc.y, cc.z), base + s, P.U[r], P.c[r]);
     }
   }
   base += S.n_triF;
@@ -267,33 +325,94 @@ __device__ __forceinline__ Closest closest_hit(const SceneDev& S, float ox, floa
     c_i32p gid = AS_CONST(c_i32p, S.mtri_gid);
     c_i32p pobj = AS_CONST(c_i32p, S.prim_obj);
     for (int s = 0; s < S.n_mtri; ++s) {
-      v4f a = tp[4 * s], b = tp[4 * s + 1], c = tp[4 * s + 2], m = tp[4 * s + 3];
-      float tm = motion_time(scan_word, (uint32_t)pobj[gid[s]]);
-      cull_tri(ox, oy, oz, dx, dy, dz, mk3(fmaf(m.x, tm, a.x), fmaf(m.y, tm, a.y), fmaf(m.z, tm, a.z)),
-               mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), base + s, best_t, best_i);
+      v4f a = tp[4 * s], b = tp[4 * s + 1], cc = tp[4 * s + 2], m = tp[4 * s + 3];
+      uint32_t obj = (uint32_t)pobj[gid[s]];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float tm = motion_time(P.word[r], obj);
+        tri_candidate(S, P.ox[r], P.oy[r], P.oz[r], P.dx[r], P.dy[r], P.dz[r],
+                      mk3(fmaf(m.x, tm, a.x), fmaf(m.y, tm, a.y), fmaf(m.z, tm, a.z)), mk3(b.x, b.y, b.z),
+                      mk3(cc.x, cc.y, cc.z), base + s, P.U[r], P.c[r]);
+      }
     }
   }
-  // 3. exact evaluation of the f32 winner, merged with the precise result
+}
+
+__device__ __forceinline__ int list_to_gid(const SceneDev& S, int i) {
+  if (i < S.n_sphF) return S.sphF_gid[i];
+  if ((i -= S.n_sphF) < S.n_msph) return S.msph_gid[i];
+  if ((i -= S.n_msph) < S.n_triF) return S.triF_gid[i];
+  return S.mtri_gid[i - S.n_triF];
+}
+
+// Before the scan: the precise spheres, exactly; sets the ray's margins and upper bound.
+__device__ __forceinline__ Closest ray_prologue(const SceneDev& S, float ox, float oy, float oz, float dx, float dy,
+                                                float dz, uint32_t word, float* negE, float* U) {
+  d3 o = d3{(double)ox, (double)oy, (double)oz};
+  d3 d = d3{(double)dx, (double)dy, (double)dz};
   Closest r;
-  r.t = Tp;
-  r.g = gp;
-  if (best_i >= 0) {
-    int g;
-    int i = best_i;
-    if (i < S.n_sphF) g = S.sphF_gid[i];
-    else if ((i -= S.n_sphF) < S.n_msph) g = S.msph_gid[i];
-    else if ((i -= S.n_msph) < S.n_triF) g = S.triF_gid[i];
-    else g = S.mtri_gid[i - S.n_triF];
+  r.t = __builtin_inf();
+  r.g = -1;
+  for (int k = 0; k < S.n_prec; ++k) {
+    int g = AS_CONST(c_i32p, S.prec_gid)[k];
     double t;
-    if (exact_prim(S, g, o, d, scan_word, &t)) {
-      if (gp < 0 || t < Tp || (t == Tp && S.prim_obj[g] < S.prim_obj[gp])) { r.t = t; r.g = g; }
-    } else {
-      // the f32 estimate named a primitive the exact test rejects: decide everything in f64
-      exact_scan_all(S, o, d, scan_word, &r.t, &r.g);
-      if (rescans) atomicAdd(rescans, 1u);
+    if (exact_prim(S, g, o, d, word, &t)) {
+      if (t < r.t || (t == r.t && S.prim_obj[g] < S.prim_obj[r.g])) { r.t = t; r.g = g; }
+    }
+  }
+  // |q| <= |oc| <= dist(origin, bounding sphere centre of the f32 sphere list) + its radius
+  float bx = ox - S.bcx, by = oy - S.bcy, bz = oz - S.bcz;
+  float dist = sqrtf(fmaf(bz, bz, fmaf(by, by, bx * bx))) * 1.000001f + S.brad;
+  *negE = -fmaf(dist, S.K1, S.K2);
+  float u = (float)r.t;                      // round to nearest, then push up past the f64 value
+  *U = (r.g >= 0) ? fmaf(fabsf(u), CFT_U4EPS, u) + 1e-30f : __builtin_inff();
+  return r;
+}
+
+// After the scan: exact evaluation of the two best candidates, rescan if a third could still win.
+// stats[0] += second evaluations, stats[1] += rescans.
+__device__ __forceinline__ Closest ray_epilogue(const SceneDev& S, float ox, float oy, float oz, float dx, float dy,
+                                                float dz, uint32_t word, const Cand& c, Closest r, uint32_t* stats) {
+  d3 o = d3{(double)ox, (double)oy, (double)oz};
+  d3 d = d3{(double)dx, (double)dy, (double)dz};
+  if (c.i1 >= 0) {
+    int g = list_to_gid(S, c.i1);
+    double t;
+    if (exact_prim(S, g, o, d, word, &t) &&
+        (r.g < 0 || t < r.t || (t == r.t && S.prim_obj[g] < S.prim_obj[r.g]))) { r.t = t; r.g = g; }
+  }
+  const bool second = c.i2 >= 0 && (double)c.lo2 <= r.t;
+  if (second) {
+    int g = list_to_gid(S, c.i2);
+    double t;
+    if (exact_prim(S, g, o, d, word, &t) &&
+        (r.g < 0 || t < r.t || (t == r.t && S.prim_obj[g] < S.prim_obj[r.g]))) { r.t = t; r.g = g; }
+  }
+  const bool rescan = c.lo3 < __builtin_inff() && (double)c.lo3 <= r.t;   // lo3 = +inf unless a third candidate exists
+  if (rescan) exact_scan_all(S, o, d, word, &r.t, &r.g);
+  if (stats) {
+    unsigned long long m2 = __ballot(second), m3 = __ballot(rescan);
+    if (m2 | m3) {
+      const uint32_t leader = (uint32_t)__ffsll((long long)__ballot(1)) - 1u;   // first active lane
+      if ((threadIdx.x & 63u) == leader) {
+        if (m2) atomicAdd(&stats[0], (uint32_t)__popcll(m2));
+        if (m3) atomicAdd(&stats[1], (uint32_t)__popcll(m3));
+      }
     }
   }
   return r;
+}
+
+// Ray::hit for one ray (used by the parity hook and the shadow kernel).
+__device__ __forceinline__ Closest closest_hit(const SceneDev& S, float ox, float oy, float oz, float dx,
+                                               float dy, float dz, uint32_t scan_word, uint32_t* stats) {
+  RayPack<1> P;
+  P.ox[0] = ox; P.oy[0] = oy; P.oz[0] = oz; P.dx[0] = dx; P.dy[0] = dy; P.dz[0] = dz;
+  P.word[0] = scan_word;
+  cand_init(P.c[0]);
+  Closest r = ray_prologue(S, ox, oy, oz, dx, dy, dz, scan_word, &P.negE[0], &P.U[0]);
+  scan_lists<1>(S, P);
+  return ray_epilogue(S, ox, oy, oz, dx, dy, dz, scan_word, P.c[0], r, stats);
 }
 
 // ------------------------------------------------------------------ generate
@@ -343,35 +462,81 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_generate(CamDev C, uint64_t pid_b
 }
 
 // ------------------------------------------------------------------ intersect
-// one lane = one live ray of trace level `level`; the primitive lists are wave-uniform operands.
-// role_a / role_b: scan numbers (motion-time keys) of the lights' `looked` scan and of trace's own
-// scan; for a static scene both scans are identical and only one is run.
+// Unit normal of prim g at hit point p for the hit record: differences in f64, normalised in f32
+// (k_shade re-normalises, as HitInfo::new does).
+__device__ __forceinline__ f3 hit_normal(const SceneDev& S, int g, d3 p, uint32_t word) {
+  d3 n;
+  if (g < S.n_sph) {
+    const double* sp = S.sphD + 4 * (size_t)g;
+    d3 c = ld3(sp);
+    if (S.any_motion) {
+      d3 mv = ld3(S.sphMvD + 3 * (size_t)g);
+      if (mv.x != 0. || mv.y != 0. || mv.z != 0.) c = c + mv * (double)motion_time(word, (uint32_t)S.prim_obj[g]);
+    }
+    n = p - c;
+    if (sp[3] < 0.) n = d3{-n.x, -n.y, -n.z};
+  } else {
+    const double* tp = S.triD + 9 * (size_t)(g - S.n_sph);
+    d3 p0 = ld3(tp), p1 = ld3(tp + 3), p2 = ld3(tp + 6);
+    n = dcross(p1 - p0, p2 - p0);
+  }
+  f3 nf = mk3((float)n.x, (float)n.y, (float)n.z);
+  float s = fmaxf(fmaxf(fabsf(nf.x), fabsf(nf.y)), fabsf(nf.z));   // keep |n|^2 inside the f32 range
+  float is = 1.0f / s;
+  nf = nf * is;
+  return nf * (1.0f / sqrtf(dot3(nf, nf)));
+}
+
+// one lane = R live rays of trace level `level` (ray i, i + stride, ...); primitive lists are
+// wave-uniform SGPR operands.  `role` numbers the scan inside the level (motion-time key).
+template <int R>
 __global__ __launch_bounds__(CFT_BLOCK) void k_intersect(SceneDev S, QueueDev q, const uint32_t* counts,
                                                          uint32_t level, uint64_t pid_base, uint32_t k0,
-                                                         uint32_t k1, uint32_t role, HitDev out,
-                                                         uint32_t* rescans) {
-  uint32_t n = counts[level];
-  for (uint32_t i = blockIdx.x * CFT_BLOCK + threadIdx.x; i < n; i += gridDim.x * CFT_BLOCK) {
-    float4 a = q.a[i];
-    float4 b = q.b[i];
-    uint32_t scan_word = 0;
-    if (S.any_motion) {
-      uint64_t pid = pid_base + __float_as_uint(q.c[i].y);
-      scan_word = philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), level, CFT_PURPOSE_SCAN0 + role, k0, k1).x;
+                                                         uint32_t k1, uint32_t role, HitDev out, uint32_t* stats) {
+  const uint32_t n = counts[level];
+  const uint32_t stride = gridDim.x * CFT_BLOCK;
+  for (uint32_t base = blockIdx.x * CFT_BLOCK + threadIdx.x; base < n; base += stride * R) {
+    RayPack<R> P;
+    Closest pre[R];
+    bool valid[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint32_t i = base + r * stride;
+      valid[r] = i < n;
+      P.ox[r] = 0.f; P.oy[r] = 0.f; P.oz[r] = 0.f; P.dx[r] = 0.f; P.dy[r] = 0.f; P.dz[r] = 1.f;
+      P.word[r] = 0; P.negE[r] = __builtin_inff(); P.U[r] = 0.f;
+      pre[r].t = __builtin_inf(); pre[r].g = -1;
+      cand_init(P.c[r]);
+      if (valid[r]) {
+        float4 a = q.a[i];
+        float4 b = q.b[i];
+        P.ox[r] = a.x; P.oy[r] = a.y; P.oz[r] = a.z; P.dx[r] = a.w; P.dy[r] = b.x; P.dz[r] = b.y;
+        if (S.any_motion) {
+          uint64_t pid = pid_base + __float_as_uint(q.c[i].y);
+          P.word[r] = philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), level, CFT_PURPOSE_SCAN0 + role, k0, k1).x;
+        }
+        pre[r] = ray_prologue(S, P.ox[r], P.oy[r], P.oz[r], P.dx[r], P.dy[r], P.dz[r], P.word[r], &P.negE[r], &P.U[r]);
+      }
     }
-    Closest c = closest_hit(S, a.x, a.y, a.z, a.w, b.x, b.y, scan_word, rescans);
-    float4 h0 = make_float4(__builtin_inff(), __int_as_float(-1), 0.f, 0.f);
-    float4 h1 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c.g >= 0) {
-      d3 o = d3{(double)a.x, (double)a.y, (double)a.z};
-      d3 d = d3{(double)a.w, (double)b.x, (double)b.y};
-      d3 p = o + d * c.t;                        // point = pos + dir * t
-      d3 nn = exact_normal(S, c.g, p, scan_word);
-      h0 = make_float4((float)c.t, __int_as_float(c.g), (float)p.x, (float)p.y);
-      h1 = make_float4((float)p.z, (float)nn.x, (float)nn.y, (float)nn.z);
+    scan_lists<R>(S, P);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (!valid[r]) continue;
+      const uint32_t i = base + r * stride;
+      Closest c = ray_epilogue(S, P.ox[r], P.oy[r], P.oz[r], P.dx[r], P.dy[r], P.dz[r], P.word[r], P.c[r], pre[r], stats);
+      float4 h0 = make_float4(__builtin_inff(), __int_as_float(-1), 0.f, 0.f);
+      float4 h1 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c.g >= 0) {
+        d3 o = d3{(double)P.ox[r], (double)P.oy[r], (double)P.oz[r]};
+        d3 d = d3{(double)P.dx[r], (double)P.dy[r], (double)P.dz[r]};
+        d3 p = o + d * c.t;                        // point = pos + dir * t
+        f3 nn = hit_normal(S, c.g, p, P.word[r]);
+        h0 = make_float4((float)c.t, __int_as_float(c.g), (float)p.x, (float)p.y);
+        h1 = make_float4((float)p.z, nn.x, nn.y, nn.z);
+      }
+      out.h0[i] = h0;
+      out.h1[i] = h1;
     }
-    out.h0[i] = h0;
-    out.h1[i] = h1;
   }
 }
 
@@ -381,14 +546,14 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_intersect_hook(SceneDev S, const 
                                                               uint64_t pid0, uint32_t level, uint32_t role,
                                                               uint32_t k0, uint32_t k1, int32_t* out_id,
                                                               double* out_t, float* out_n, float* out_p,
-                                                              uint32_t* rescans) {
+                                                              uint32_t* stats) {
   for (uint32_t i = blockIdx.x * CFT_BLOCK + threadIdx.x; i < n; i += gridDim.x * CFT_BLOCK) {
     const float* r = rays + 6 * (size_t)i;
     float ox = r[0], oy = r[1], oz = r[2], dx = r[3], dy = r[4], dz = r[5];
     uint64_t pid = pid0 + i;
     uint32_t scan_word =
         philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), level, CFT_PURPOSE_SCAN0 + role, k0, k1).x;
-    Closest c = closest_hit(S, ox, oy, oz, dx, dy, dz, scan_word, rescans);
+    Closest c = closest_hit(S, ox, oy, oz, dx, dy, dz, scan_word, stats);
     d3 nn = d3{0., 0., 0.}, p = d3{0., 0., 0.};
     if (c.g >= 0) {
       d3 o = d3{(double)ox, (double)oy, (double)oz};
@@ -610,11 +775,11 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_shade(SceneDev S, QueueDev qin, H
 
 // ------------------------------------------------------------------ shadow (PhongModel::render)
 // one lane = one Phong hit; loops over the lights (basic.rs:57-94).  Every (hit, light) pair scans
-// one ray against the world: the mirror ray (sky / shape lights) or the ray towards the light
-// (point / parallel lights).
+// one ray against the world: the mirror ray (sky / shape lights: `looked`, then `is_in_shadow` on the
+// same ray) or the ray towards the light (point / parallel lights).
 __global__ __launch_bounds__(CFT_BLOCK) void k_shadow(SceneDev S, PhongQueueDev pq, const uint32_t* phong_counts,
                                                       uint32_t level, uint64_t pid_base, uint32_t k0, uint32_t k1,
-                                                      float4* radiance, uint32_t* rescans) {
+                                                      float4* radiance, uint32_t* stats) {
   uint32_t n = phong_counts[level];
   uint32_t nl = (uint32_t)S.n_lights;
   for (uint32_t i = blockIdx.x * CFT_BLOCK + threadIdx.x; i < n; i += gridDim.x * CFT_BLOCK) {
@@ -633,44 +798,34 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_shadow(SceneDev S, PhongQueueDev 
         wl = philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), level, CFT_PURPOSE_SCAN0 + nl + 1 + 2 * j, k0, k1).x;
         ws = philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), level, CFT_PURPOSE_SCAN0 + nl + 2 + 2 * j, k0, k1).x;
       }
-      f3 ldir, lcol;
-      float inten;
+      const bool mirror = L.kind == 0 || L.kind == 1;
+      f3 lp = mk3(L.vx, L.vy, L.vz);
+      f3 ldir = (L.kind == 2) ? unit3(pos - lp) : (L.kind == 3 ? lp : -dout);   // dir_at(hit)
+      f3 rd = mirror ? dout : unit3(-ldir);                                      // the ray scanned
+      Closest h1 = closest_hit(S, pos.x, pos.y, pos.z, rd.x, rd.y, rd.z, mirror ? wl : ws, stats);
+      Closest h2 = h1;
+      if (S.any_motion && mirror) h2 = closest_hit(S, pos.x, pos.y, pos.z, rd.x, rd.y, rd.z, ws, stats);
+      f3 lcol = mk3(L.r, L.g, L.b);
+      float inten = 1.0f;
       bool shadow;
-      if (L.kind == 0) {            // SkyLight
-        Closest hl = closest_hit(S, pos.x, pos.y, pos.z, dout.x, dout.y, dout.z, wl, rescans);
-        if (hl.g < 0) { sum = sum + sky_color_from(dout); continue; }     // looked(reflect) -> return c
-        ldir = -dout; lcol = sky_color_from(dout); inten = 1.0f;
-        if (S.any_motion) shadow = closest_hit(S, pos.x, pos.y, pos.z, dout.x, dout.y, dout.z, ws, rescans).g >= 0;
-        else shadow = true;         // same ray, same static world: it hit
-      } else if (L.kind == 1) {     // LightShape
+      if (L.kind == 0) {            // SkyLight, light.rs:166-191
+        if (h1.g < 0) { sum = sum + sky_color_from(dout); continue; }          // looked(reflect) -> return c
+        lcol = sky_color_from(dout);
+        shadow = h2.g >= 0;
+      } else if (L.kind == 1) {     // LightShape, light.rs:207-243
         double tl;
         bool hs = light_shape_hit(S, L, pos, dout, &tl);
-        Closest hw = closest_hit(S, pos.x, pos.y, pos.z, dout.x, dout.y, dout.z, wl, rescans);
-        if (hs && (hw.g < 0 || tl < hw.t)) { sum = sum + mk3(L.r, L.g, L.b); continue; }
-        ldir = -dout; lcol = mk3(L.r, L.g, L.b); inten = hs ? 1.0f : 0.0f;
-        Closest h2 = S.any_motion ? closest_hit(S, pos.x, pos.y, pos.z, dout.x, dout.y, dout.z, ws, rescans) : hw;
+        if (hs && (h1.g < 0 || tl < h1.t)) { sum = sum + lcol; continue; }
+        inten = hs ? 1.0f : 0.0f;
         shadow = h2.g >= 0 && hs && h2.t < tl;
       } else if (L.kind == 2) {     // PointLight, light.rs:111-135
-        f3 lp = mk3(L.vx, L.vy, L.vz);
-        ldir = unit3(pos - lp);
-        lcol = mk3(L.r, L.g, L.b);
         f3 dl = lp - pos;
-        inten = 1.0f / dot3(dl, dl);
-        f3 rd = unit3(-ldir);
-        Closest hw = closest_hit(S, pos.x, pos.y, pos.z, rd.x, rd.y, rd.z, ws, rescans);
-        shadow = false;
-        if (hw.g >= 0) {
-          float t = (float)hw.t;
-          f3 hp = madd3(pos, rd, t) - pos;                 // point - hit.pos() (un-offset hit point)
-          float l1 = dot3(hp, hp), l2 = dot3(dl, dl);
-          shadow = l1 + CFT_EPS < l2;
-        }
+        float l2 = dot3(dl, dl);
+        inten = 1.0f / l2;
+        float t = (float)h1.t;      // |point - hit.pos()|^2 = t^2 for the unit ray
+        shadow = h1.g >= 0 && (t * t + CFT_EPS < l2);
       } else {                      // ParallelLight, light.rs:86-102
-        ldir = mk3(L.vx, L.vy, L.vz);
-        lcol = mk3(L.r, L.g, L.b);
-        inten = 1.0f;
-        f3 rd = unit3(-ldir);
-        shadow = closest_hit(S, pos.x, pos.y, pos.z, rd.x, rd.y, rd.z, ws, rescans).g >= 0;
+        shadow = h1.g >= 0;
       }
       float ratio2 = dot3(dout, -ldir);
       float ratio = powf(ratio2, m.p0);

@@ -59,6 +59,13 @@ struct SceneDev {
   const double* ltriD;    // light-shape triangles, 9 each
   int any_motion;
   int n_phong_mats;
+  // ---- f32 error model of the cull, set by cftrt_scene_commit ----
+  float K1, K2;            // |disc - true disc| <= K1*|q| + K2
+  float K3, K4;            // |q - true q|       <= K3*|q| + K4
+  float bcx, bcy, bcz, brad;   // bounding sphere of the f32 sphere lists (centres + radii + motion)
+  float tKA;               // |a - true a| (triangle determinant)
+  float tKU1, tKU2;        // |u,v - true| <= |f| * (tKU1*|s|_1 + tKU2)
+  float tKT1, tKT2, tKT3;  // |t - true t| <= |f| * (tKT1*|s|_1 + tKT2 + tKT3*|t|)
 };
 
 // Ray queue slot: 40 B in three coalesced streams.
