@@ -50,6 +50,18 @@ def cpu_baseline():
                       "the Rust reference, std::thread over rows)"}
 
 
+def hbm_traffic_per_launch(rays_per_step, launches_per_step):
+    """HBM bytes per k_intersect launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled for gfx950,
+    WRITE_SIZE as is; profiles/r01_hbm_traffic.json) scaled to this run's ray count; None if absent.
+    PMC counters cannot be read inside the timed run."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    try:
+        k = json.load(open(path))["kernels"]["k_intersect<2>"]
+    except (OSError, KeyError, ValueError):
+        return None
+    return k["bytes_per_ray"] * rays_per_step / max(launches_per_step, 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,7 +156,7 @@ def main():
                        "exact_rescans": int(s0.exact_rescan)},
             "roofline": {"bound": "valu_fp32", "kernel": "k_intersect", "achieved": achieved,
                          "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
-                         "traffic": None,
+                         "traffic": hbm_traffic_per_launch(int(s0.rays), n_launch // max(args.steps, 1)),
                          "launches": n_launch, "avg_launch_ms": ms_isect / max(n_launch, 1),
                          "algorithmic_flops_per_launch": fl_isect / max(n_launch, 1),
                          "flops_per_ray": 16 * 500, "whole_loop_tflops": sum(s.flops for s in stats) / elapsed_max / 1e12},

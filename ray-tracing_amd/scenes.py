@@ -23,6 +23,10 @@ def _philox_word0(i, seed):
     return c0
 
 
+def _sq(x):
+    return x * x   # f64::powi(2)
+
+
 class Rd:
     """`rng.gen::<f64>()` stand-in: sequential uniform draws in [0,1)."""
 
@@ -46,7 +50,7 @@ def _rtiow_spheres(world, rd, motion, lo=-11, hi=11):
             center = (a + 0.9 * rd(), b + 0.9 * rd(), 0.2)
             choose = rd()
             if choose < 0.8:
-                col = (rd() ** 2, rd() ** 2, rd() ** 2)
+                col = (_sq(rd()), _sq(rd()), _sq(rd()))
                 obj = A.Object(A.Sphere(center, 0.2), d.with_color(col))
             elif choose < 0.95:
                 col = ((1.0 + rd()) / 2.0, (1.0 + rd()) / 2.0, (1.0 + rd()) / 2.0)
@@ -109,7 +113,7 @@ def s500(seed=SCENE_SEED, width=1920, height=1080, spp=64):
     d = A.LambertianModel(1.0)
     for b in range(-11, 1):
         center = (11 + 0.9 * rd(), b + 0.9 * rd(), 0.2)
-        col = (rd() ** 2, rd() ** 2, rd() ** 2)
+        col = (_sq(rd()), _sq(rd()), _sq(rd()))
         world.add_obj(A.Object(A.Sphere(center, 0.2), d.with_color(col)))
     world.add_light(A.SkyLight())
     camera = (A.Camera.new((13.0, -3.0, 2.0), (0.0, 0.0, 0.0)).with_focus_dist(10.0).with_aperture(0.1)
@@ -131,7 +135,7 @@ def s20k(seed=SCENE_SEED + 1, width=1920, height=1080, spp=64, n_spheres=19000, 
     def material():
         choose = rd()
         if choose < 0.8:
-            return d.with_color((rd() ** 2, rd() ** 2, rd() ** 2))
+            return d.with_color((_sq(rd()), _sq(rd()), _sq(rd())))
         if choose < 0.95:
             return m.with_color(((1.0 + rd()) / 2.0, (1.0 + rd()) / 2.0, (1.0 + rd()) / 2.0)).with_fuzz(rd() / 2.0)
         return t
