@@ -292,7 +292,8 @@ int cftrt_scene_commit(cftrt_scene* s) {
   for (int i = 0; i < nt; ++i)
     if (s->tri_mat[i] >= nm) return fail(ctx, CFTRT_ERR_INVALID, "triangle mat_id beyond the material table");
 
-  std::vector<float4> sphF, msphF, msphMv, triF, mtriF;
+  std::vector<float4> sphF, msphF, triF, mtriF;
+  int prec_motion = 0;
   std::vector<int> sphF_gid, msph_gid, prec_gid, triF_gid, mtri_gid, prim_obj(ns + nt), prim_mat(ns + nt);
   std::vector<double> sphD(4 * (size_t)ns);
   int any_motion = 0;
@@ -307,9 +308,12 @@ int cftrt_scene_commit(cftrt_scene* s) {
     if (moving) any_motion = 1;
     if (std::fabs(r) >= s->precise_radius) {
       prec_gid.push_back(i);
+      if (moving) prec_motion = 1;
     } else if (moving) {
+      float objbits;
+      memcpy(&objbits, &s->sph_obj[i], 4);
       msphF.push_back(make_float4((float)c[0], (float)c[1], (float)c[2], (float)(r * r)));
-      msphMv.push_back(make_float4((float)mv[0], (float)mv[1], (float)mv[2], 0.f));
+      msphF.push_back(make_float4((float)mv[0], (float)mv[1], (float)mv[2], objbits));
       msph_gid.push_back(i);
     } else {
       sphF.push_back(make_float4((float)c[0], (float)c[1], (float)c[2], (float)(r * r)));
@@ -328,13 +332,17 @@ int cftrt_scene_commit(cftrt_scene* s) {
     if (moving) {
       any_motion = 1;
       mtriF.push_back(P0); mtriF.push_back(E1); mtriF.push_back(E2);
-      mtriF.push_back(make_float4((float)mv[0], (float)mv[1], (float)mv[2], 0.f));
+      float objbits;
+      memcpy(&objbits, &s->tri_obj[i], 4);
+      mtriF.push_back(make_float4((float)mv[0], (float)mv[1], (float)mv[2], objbits));
       mtri_gid.push_back(ns + i);
     } else {
       triF.push_back(P0); triF.push_back(E1); triF.push_back(E2);
       triF_gid.push_back(ns + i);
     }
   }
+  msphF.push_back(make_float4(0.f, 0.f, 0.f, -1e30f));   // the prefetched extra entry of the moving list
+  msphF.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
   const int n_sphF_real = (int)sphF_gid.size();
   while (sphF.size() % 4) sphF.push_back(make_float4(0.f, 0.f, 0.f, -1e30f));   // never hit: disc = -1e30 - |l|^2
   for (int k = 0; k < 4; ++k) sphF.push_back(make_float4(0.f, 0.f, 0.f, -1e30f));   // the prefetched extra batch
@@ -358,7 +366,6 @@ int cftrt_scene_commit(cftrt_scene* s) {
   if ((rc = upload(s, sphF, &D.sphF))) return rc;
   if ((rc = upload(s, sphF_gid, &D.sphF_gid))) return rc;
   if ((rc = upload(s, msphF, &D.msphF))) return rc;
-  if ((rc = upload(s, msphMv, &D.msphMv))) return rc;
   if ((rc = upload(s, msph_gid, &D.msph_gid))) return rc;
   if ((rc = upload(s, prec_gid, &D.prec_gid))) return rc;
   if ((rc = upload(s, triF, &D.triF))) return rc;
@@ -385,6 +392,7 @@ int cftrt_scene_commit(cftrt_scene* s) {
   D.n_mat = nm;
   D.n_lights = (int)lights.size();
   D.any_motion = any_motion;
+  D.prec_motion = prec_motion;
   D.n_phong_mats = n_phong;
   {
     // f32 error model of the cull.  eps = 2^-24 (unit roundoff); every constant carries
@@ -486,19 +494,27 @@ static uint32_t grid_for(cftrt_ctx* ctx, uint64_t n, uint32_t per_cu) {
 }
 
 
-// k_intersect<R>: R rays per lane.  ctx->variant picks R (0 = default).
+// k_intersect<R, NS>: R rays per lane (ctx->variant, 0 = default), NS scans per ray in one pass.
 static void launch_intersect(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, const uint32_t* counts, uint32_t level,
-                             uint64_t pid_base, uint32_t k0, uint32_t k1, uint32_t role, HitDev out, uint32_t* xstats,
-                             uint32_t P) {
-  const int R = ctx->variant ? ctx->variant : CFT_RAYS_PER_LANE;
+                             uint64_t pid_base, uint32_t k0, uint32_t k1, bool two_scans, uint32_t role0, uint32_t role1,
+                             HitDev out0, HitDev out1, uint32_t* xstats, uint32_t P) {
+  int R = ctx->variant ? ctx->variant : CFT_RAYS_PER_LANE;
+  if (two_scans && R > 2) R = 2;
   const uint32_t g = grid_for(ctx, ((uint64_t)P + R - 1) / R, 8);
   hipStream_t st = ctx->stream;
-  switch (R) {
-    case 1: hipLaunchKernelGGL((k_intersect<1>), dim3(g), dim3(CFT_BLOCK), 0, st, S, q, counts, level, pid_base, k0, k1, role, out, xstats); break;
-    case 3: hipLaunchKernelGGL((k_intersect<3>), dim3(g), dim3(CFT_BLOCK), 0, st, S, q, counts, level, pid_base, k0, k1, role, out, xstats); break;
-    case 4: hipLaunchKernelGGL((k_intersect<4>), dim3(g), dim3(CFT_BLOCK), 0, st, S, q, counts, level, pid_base, k0, k1, role, out, xstats); break;
-    default: hipLaunchKernelGGL((k_intersect<2>), dim3(g), dim3(CFT_BLOCK), 0, st, S, q, counts, level, pid_base, k0, k1, role, out, xstats); break;
+#define CFT_LAUNCH(RR, NN) hipLaunchKernelGGL((k_intersect<RR, NN>), dim3(g), dim3(CFT_BLOCK), 0, st, S, q, counts, level, \
+                                              pid_base, k0, k1, role0, role1, out0, out1, xstats)
+  if (two_scans) {
+    if (R == 1) CFT_LAUNCH(1, 2); else CFT_LAUNCH(2, 2);
+  } else {
+    switch (R) {
+      case 1: CFT_LAUNCH(1, 1); break;
+      case 3: CFT_LAUNCH(3, 1); break;
+      case 4: CFT_LAUNCH(4, 1); break;
+      default: CFT_LAUNCH(2, 1); break;
+    }
   }
+#undef CFT_LAUNCH
 }
 
 struct EvTimer {   // pairs of events around launches on the ctx stream, summed per class after a sync
@@ -584,8 +600,7 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
     int in = level & 1, outq = in ^ 1;
     const uint32_t nl = (uint32_t)S.n_lights;
     tm.begin(CLS_ISECT);
-    if (two_scans) launch_intersect(ctx, S, q[in], counts, level, pid_base, k0, k1, 0u, hA, xstats, P);
-    launch_intersect(ctx, S, q[in], counts, level, pid_base, k0, k1, nl, hB, xstats, P);
+    launch_intersect(ctx, S, q[in], counts, level, pid_base, k0, k1, two_scans, two_scans ? 0u : nl, nl, hA, hB, xstats, P);
     tm.end();
     tm.begin(CLS_SHADE);
     hipLaunchKernelGGL(k_shade, dim3(grid), dim3(CFT_BLOCK), 0, st_, S, q[in], hA, hB, counts, level, max_depth, pid_base,

@@ -183,14 +183,16 @@ __device__ __forceinline__ void cand_insert(Cand& c, float tlo, int idx) {
 
 #define CFT_U4EPS 2.3841858e-7f   // 4 * 2^-24: slack for a 1-ulp sqrt/rcp and the final adds
 
-// A sphere the fast path could not rule out (disc >= -E_ray): turn (q, disc) into a lower bound.
+// A sphere the fast path could not rule out (disc >= -E_ray): turn (q, disc) into a lower bound on its hit
+// distance, or -1 when it certainly is no hit nearer than U.
 //   q = oc.d,  disc = r^2 - |oc - q d|^2  (both f32, error model in DESIGN.md §4)
-__device__ __forceinline__ void sphere_candidate(const SceneDev& S, float q, float d, int idx, float U, Cand& c) {
+__device__ __forceinline__ float sphere_lower_bound(const SceneDev& S, float q, float d, float U) {
   const float aq = fabsf(q);
   const float e = fmaf(aq, S.K1, S.K2);                 // |disc - true disc| <= e
   const float eq = fmaf(aq, S.K3, S.K4);                // |q - true q| <= eq
   const bool inside = fmaf(-q, q, d) > e;               // r^2 - |oc|^2 = disc - q^2 certainly > 0
   const float arg = inside ? fmaxf(d - e, 0.0f) : d + e;
+  float r = -1.0f;
   if (arg >= 0.0f) {
     const float s = __builtin_amdgcn_sqrtf(arg);
     const float s_hi = fmaf(s, CFT_U4EPS, s), s_lo = fmaf(-s, CFT_U4EPS, s);
@@ -199,16 +201,19 @@ __device__ __forceinline__ void sphere_candidate(const SceneDev& S, float q, flo
     tlo = tlo - eq - fabsf(tlo) * CFT_U4EPS;
     const bool possible = inside || (s_hi - q + eq >= 0.0f);   // t2 could be >= 0
     tlo = fmaxf(tlo, 0.0f);
-    if (possible && tlo <= U) cand_insert(c, tlo, idx);
+    if (possible && tlo <= U) r = tlo;
   }
+  return r;
 }
 
-// Moller-Trumbore in f32 with explicit error margins (triangle = p0, e1, e2).
-__device__ __forceinline__ void tri_candidate(const SceneDev& S, float ox, float oy, float oz, float dx, float dy,
-                                              float dz, f3 p0, f3 e1, f3 e2, int idx, float U, Cand& c) {
+// Moller-Trumbore in f32 with explicit error margins (triangle = p0, e1, e2): lower bound on the hit
+// distance, or -1.
+__device__ __forceinline__ float tri_lower_bound(const SceneDev& S, float ox, float oy, float oz, float dx, float dy,
+                                                 float dz, f3 p0, f3 e1, f3 e2, float U) {
   f3 d = mk3(dx, dy, dz);
   f3 h = cross3(d, e2);
   float a = dot3(e1, h);
+  float r = -1.0f;
   if (fabsf(a) >= CFT_EPS - S.tKA) {                    // the reference rejects |a| < EPS (object.rs:105)
     float f = __builtin_amdgcn_rcpf(a);
     float af = fabsf(f);
@@ -222,9 +227,10 @@ __device__ __forceinline__ void tri_candidate(const SceneDev& S, float ox, float
     float mt = af * fmaf(fabsf(t), S.tKT3, fmaf(s1, S.tKT1, S.tKT2));   // |t - true t| <= mt
     if (u >= -mu && v >= -mu && u <= 1.0f + mu && u + v <= 1.0f + 2.0f * mu && t + mt > CFT_EPS) {
       float tlo = fmaxf(t - mt, 0.0f);
-      if (tlo <= U) cand_insert(c, tlo, idx);
+      if (tlo <= U) r = tlo;
     }
   }
+  return r;
 }
 
 struct Closest {
@@ -233,18 +239,20 @@ struct Closest {
 };
 
 // R rays per lane: the wave-uniform sphere operands (SGPRs) are fetched once for R tests, and one
-// uniform branch per sphere serves all of them.
-template <int R>
+// uniform branch per sphere serves all of them.  NS scans per ray: the reference scans the world up to
+// twice per trace level (the lights' `looked`, then trace's own Ray::hit), each with fresh motion times;
+// static primitives are tested once and feed both candidate sets, moving ones are tested per scan.
+template <int R, int NS>
 struct RayPack {
   float ox[R], oy[R], oz[R], dx[R], dy[R], dz[R];
-  float negE[R];      // -(fast-path margin) of the ray: candidates have disc >= negE
-  float U[R];         // upper bound on the winner's distance (exact precise-sphere hit), f32 rounded up
-  uint32_t word[R];   // motion key of this scan
-  Cand c[R];
+  float negE[R];          // -(fast-path margin) of the ray: candidates have disc >= negE
+  float U[R];             // upper bound on the winner's distance (exact precise-sphere hit), f32 rounded up
+  uint32_t word[NS][R];   // motion key of each scan
+  Cand c[NS][R];
 };
 
-template <int R>
-__device__ __forceinline__ void scan_sphere(const SceneDev& S, RayPack<R>& P, float negEmin, float cx, float cy,
+template <int R, int NS>
+__device__ __forceinline__ void scan_sphere(const SceneDev& S, RayPack<R, NS>& P, float negEmin, float cx, float cy,
                                             float cz, float r2, int idx) {
   float q[R], d[R];
   float m = -__builtin_inff();
@@ -259,13 +267,22 @@ __device__ __forceinline__ void scan_sphere(const SceneDev& S, RayPack<R>& P, fl
   if (__ballot(m >= negEmin) != 0ull) {
 #pragma unroll
     for (int r = 0; r < R; ++r)
-      if (d[r] >= P.negE[r]) sphere_candidate(S, q[r], d[r], idx, P.U[r], P.c[r]);
+      if (d[r] >= P.negE[r]) {
+        float tlo = sphere_lower_bound(S, q[r], d[r], P.U[r]);
+        if (tlo >= 0.0f) {
+#pragma unroll
+          for (int k = 0; k < NS; ++k) cand_insert(P.c[k][r], tlo, idx);
+        }
+      }
   }
 }
 
+typedef float v8f __attribute__((ext_vector_type(8)));
+typedef const v8f __attribute__((address_space(4))) * c_f8p;
+
 // f32 scan of every non-precise primitive for R rays (indices into [sphF | msph | triF | mtri]).
-template <int R>
-__device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R>& P) {
+template <int R, int NS>
+__device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P) {
   float negEmin = P.negE[0];
 #pragma unroll
   for (int r = 1; r < R; ++r) negEmin = fminf(negEmin, P.negE[r]);
@@ -278,33 +295,40 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R>& P) {
     for (int s4 = 0; s4 < n4; ++s4) {
       v16f nxt = sp[s4 + 1];
       const int s = s4 << 2;
-      scan_sphere<R>(S, P, negEmin, cur[0], cur[1], cur[2], cur[3], s);
-      scan_sphere<R>(S, P, negEmin, cur[4], cur[5], cur[6], cur[7], s + 1);
-      scan_sphere<R>(S, P, negEmin, cur[8], cur[9], cur[10], cur[11], s + 2);
-      scan_sphere<R>(S, P, negEmin, cur[12], cur[13], cur[14], cur[15], s + 3);
+      scan_sphere<R, NS>(S, P, negEmin, cur[0], cur[1], cur[2], cur[3], s);
+      scan_sphere<R, NS>(S, P, negEmin, cur[4], cur[5], cur[6], cur[7], s + 1);
+      scan_sphere<R, NS>(S, P, negEmin, cur[8], cur[9], cur[10], cur[11], s + 2);
+      scan_sphere<R, NS>(S, P, negEmin, cur[12], cur[13], cur[14], cur[15], s + 3);
       cur = nxt;
     }
   }
   int base = S.n_sphF;
-  if (S.n_msph) {   // moving spheres: centre + time * moving_to, one time per object per scan (object.rs:42-55)
-    c_f4p sp = AS_CONST(c_f4p, S.msphF);
-    c_f4p mv = AS_CONST(c_f4p, S.msphMv);
-    c_i32p gid = AS_CONST(c_i32p, S.msph_gid);
-    c_i32p pobj = AS_CONST(c_i32p, S.prim_obj);
-    for (int s = 0; s < S.n_msph; ++s) {
-      v4f cc = sp[s];
-      v4f m = mv[s];
-      uint32_t obj = (uint32_t)pobj[gid[s]];
+  if (S.n_msph) {
+    // moving spheres, 8 floats each: (cx, cy, cz, r^2, mvx, mvy, mvz, object id); centre + time * moving_to
+    // with one fresh time per object per scan (object.rs:42-55)
+    c_f8p sp = AS_CONST(c_f8p, S.msphF);
+    const int n = S.n_msph;
+    v8f cur = sp[0];
+    for (int s = 0; s < n; ++s) {
+      v8f nxt = sp[s + 1];   // padded by one entry on the host
+      const uint32_t obj = __float_as_uint(cur[7]);
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        float tm = motion_time(P.word[r], obj);
-        float cx = fmaf(m.x, tm, cc.x), cy = fmaf(m.y, tm, cc.y), cz = fmaf(m.z, tm, cc.z);
-        float ocx = P.ox[r] - cx, ocy = P.oy[r] - cy, ocz = P.oz[r] - cz;
-        float q = fmaf(ocz, P.dz[r], fmaf(ocy, P.dy[r], ocx * P.dx[r]));
-        float lx = fmaf(-q, P.dx[r], ocx), ly = fmaf(-q, P.dy[r], ocy), lz = fmaf(-q, P.dz[r], ocz);
-        float d = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, cc.w)));
-        if (d >= P.negE[r]) sphere_candidate(S, q, d, base + s, P.U[r], P.c[r]);
+      for (int k = 0; k < NS; ++k) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          float tm = motion_time(P.word[k][r], obj);
+          float cx = fmaf(cur[4], tm, cur[0]), cy = fmaf(cur[5], tm, cur[1]), cz = fmaf(cur[6], tm, cur[2]);
+          float ocx = P.ox[r] - cx, ocy = P.oy[r] - cy, ocz = P.oz[r] - cz;
+          float q = fmaf(ocz, P.dz[r], fmaf(ocy, P.dy[r], ocx * P.dx[r]));
+          float lx = fmaf(-q, P.dx[r], ocx), ly = fmaf(-q, P.dy[r], ocy), lz = fmaf(-q, P.dz[r], ocz);
+          float d = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, cur[3])));
+          if (d >= P.negE[r]) {
+            float tlo = sphere_lower_bound(S, q, d, P.U[r]);
+            if (tlo >= 0.0f) cand_insert(P.c[k][r], tlo, base + s);
+          }
+        }
       }
+      cur = nxt;
     }
   }
   base += S.n_msph;
@@ -314,25 +338,32 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R>& P) {
     for (int s = 0; s < n; ++s) {
       v4f a = tp[3 * s], b = tp[3 * s + 1], cc = tp[3 * s + 2];
 #pragma unroll
-      for (int r = 0; r < R; ++r)
-        tri_candidate(S, P.ox[r], P.oy[r], P.oz[r], P.dx[r], P.dy[r], P.dz[r], mk3(a.x, a.y, a.z),
-                      mk3(b.x, b.y, b.z), mk3(cc.x, cc.y, cc.z), base + s, P.U[r], P.c[r]);
+      for (int r = 0; r < R; ++r) {
+        float tlo = tri_lower_bound(S, P.ox[r], P.oy[r], P.oz[r], P.dx[r], P.dy[r], P.dz[r], mk3(a.x, a.y, a.z),
+                                    mk3(b.x, b.y, b.z), mk3(cc.x, cc.y, cc.z), P.U[r]);
+        if (tlo >= 0.0f) {
+#pragma unroll
+          for (int k = 0; k < NS; ++k) cand_insert(P.c[k][r], tlo, base + s);
+        }
+      }
     }
   }
   base += S.n_triF;
-  if (S.n_mtri) {
+  if (S.n_mtri) {   // moving triangles, 4 float4 each: p0, e1, e2, (mv, object id)
     c_f4p tp = AS_CONST(c_f4p, S.mtriF);
-    c_i32p gid = AS_CONST(c_i32p, S.mtri_gid);
-    c_i32p pobj = AS_CONST(c_i32p, S.prim_obj);
     for (int s = 0; s < S.n_mtri; ++s) {
       v4f a = tp[4 * s], b = tp[4 * s + 1], cc = tp[4 * s + 2], m = tp[4 * s + 3];
-      uint32_t obj = (uint32_t)pobj[gid[s]];
+      const uint32_t obj = __float_as_uint(m.w);
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        float tm = motion_time(P.word[r], obj);
-        tri_candidate(S, P.ox[r], P.oy[r], P.oz[r], P.dx[r], P.dy[r], P.dz[r],
-                      mk3(fmaf(m.x, tm, a.x), fmaf(m.y, tm, a.y), fmaf(m.z, tm, a.z)), mk3(b.x, b.y, b.z),
-                      mk3(cc.x, cc.y, cc.z), base + s, P.U[r], P.c[r]);
+      for (int k = 0; k < NS; ++k) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          float tm = motion_time(P.word[k][r], obj);
+          float tlo = tri_lower_bound(S, P.ox[r], P.oy[r], P.oz[r], P.dx[r], P.dy[r], P.dz[r],
+                                      mk3(fmaf(m.x, tm, a.x), fmaf(m.y, tm, a.y), fmaf(m.z, tm, a.z)),
+                                      mk3(b.x, b.y, b.z), mk3(cc.x, cc.y, cc.z), P.U[r]);
+          if (tlo >= 0.0f) cand_insert(P.c[k][r], tlo, base + s);
+        }
       }
     }
   }
@@ -406,13 +437,13 @@ __device__ __forceinline__ Closest ray_epilogue(const SceneDev& S, float ox, flo
 // Ray::hit for one ray (used by the parity hook and the shadow kernel).
 __device__ __forceinline__ Closest closest_hit(const SceneDev& S, float ox, float oy, float oz, float dx,
                                                float dy, float dz, uint32_t scan_word, uint32_t* stats) {
-  RayPack<1> P;
+  RayPack<1, 1> P;
   P.ox[0] = ox; P.oy[0] = oy; P.oz[0] = oz; P.dx[0] = dx; P.dy[0] = dy; P.dz[0] = dz;
-  P.word[0] = scan_word;
-  cand_init(P.c[0]);
+  P.word[0][0] = scan_word;
+  cand_init(P.c[0][0]);
   Closest r = ray_prologue(S, ox, oy, oz, dx, dy, dz, scan_word, &P.negE[0], &P.U[0]);
-  scan_lists<1>(S, P);
-  return ray_epilogue(S, ox, oy, oz, dx, dy, dz, scan_word, P.c[0], r, stats);
+  scan_lists<1, 1>(S, P);
+  return ray_epilogue(S, ox, oy, oz, dx, dy, dz, scan_word, P.c[0][0], r, stats);
 }
 
 // ------------------------------------------------------------------ generate
@@ -488,54 +519,75 @@ __device__ __forceinline__ f3 hit_normal(const SceneDev& S, int g, d3 p, uint32_
 }
 
 // one lane = R live rays of trace level `level` (ray i, i + stride, ...); primitive lists are
-// wave-uniform SGPR operands.  `role` numbers the scan inside the level (motion-time key).
-template <int R>
+// wave-uniform SGPR operands.  NS = 1: one scan with motion key `role0`.  NS = 2 (scenes with moving
+// objects AND lights): the lights' `looked` scan (role0 -> out0) and trace's own (role1 -> out1) in one pass.
+template <int R, int NS>
 __global__ __launch_bounds__(CFT_BLOCK) void k_intersect(SceneDev S, QueueDev q, const uint32_t* counts,
                                                          uint32_t level, uint64_t pid_base, uint32_t k0,
-                                                         uint32_t k1, uint32_t role, HitDev out, uint32_t* stats) {
+                                                         uint32_t k1, uint32_t role0, uint32_t role1, HitDev out0,
+                                                         HitDev out1, uint32_t* stats) {
   const uint32_t n = counts[level];
   const uint32_t stride = gridDim.x * CFT_BLOCK;
   for (uint32_t base = blockIdx.x * CFT_BLOCK + threadIdx.x; base < n; base += stride * R) {
-    RayPack<R> P;
-    Closest pre[R];
+    RayPack<R, NS> P;
+    Closest pre[NS][R];
     bool valid[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const uint32_t i = base + r * stride;
       valid[r] = i < n;
       P.ox[r] = 0.f; P.oy[r] = 0.f; P.oz[r] = 0.f; P.dx[r] = 0.f; P.dy[r] = 0.f; P.dz[r] = 1.f;
-      P.word[r] = 0; P.negE[r] = __builtin_inff(); P.U[r] = 0.f;
-      pre[r].t = __builtin_inf(); pre[r].g = -1;
-      cand_init(P.c[r]);
+      P.negE[r] = __builtin_inff(); P.U[r] = 0.f;
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        P.word[k][r] = 0;
+        pre[k][r].t = __builtin_inf(); pre[k][r].g = -1;
+        cand_init(P.c[k][r]);
+      }
       if (valid[r]) {
         float4 a = q.a[i];
         float4 b = q.b[i];
         P.ox[r] = a.x; P.oy[r] = a.y; P.oz[r] = a.z; P.dx[r] = a.w; P.dy[r] = b.x; P.dz[r] = b.y;
         if (S.any_motion) {
           uint64_t pid = pid_base + __float_as_uint(q.c[i].y);
-          P.word[r] = philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), level, CFT_PURPOSE_SCAN0 + role, k0, k1).x;
+#pragma unroll
+          for (int k = 0; k < NS; ++k)
+            P.word[k][r] = philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), level,
+                                         CFT_PURPOSE_SCAN0 + (k == 0 ? role0 : role1), k0, k1).x;
         }
-        pre[r] = ray_prologue(S, P.ox[r], P.oy[r], P.oz[r], P.dx[r], P.dy[r], P.dz[r], P.word[r], &P.negE[r], &P.U[r]);
+        pre[0][r] = ray_prologue(S, P.ox[r], P.oy[r], P.oz[r], P.dx[r], P.dy[r], P.dz[r], P.word[0][r], &P.negE[r], &P.U[r]);
+        if (NS == 2) {
+          pre[NS - 1][r] = pre[0][r];
+          if (S.prec_motion) {   // a moving precise sphere: its exact hit differs per scan; no shared bound
+            float ne, u;
+            pre[NS - 1][r] = ray_prologue(S, P.ox[r], P.oy[r], P.oz[r], P.dx[r], P.dy[r], P.dz[r], P.word[NS - 1][r], &ne, &u);
+            P.U[r] = __builtin_inff();
+          }
+        }
       }
     }
-    scan_lists<R>(S, P);
+    scan_lists<R, NS>(S, P);
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      if (!valid[r]) continue;
-      const uint32_t i = base + r * stride;
-      Closest c = ray_epilogue(S, P.ox[r], P.oy[r], P.oz[r], P.dx[r], P.dy[r], P.dz[r], P.word[r], P.c[r], pre[r], stats);
-      float4 h0 = make_float4(__builtin_inff(), __int_as_float(-1), 0.f, 0.f);
-      float4 h1 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c.g >= 0) {
-        d3 o = d3{(double)P.ox[r], (double)P.oy[r], (double)P.oz[r]};
-        d3 d = d3{(double)P.dx[r], (double)P.dy[r], (double)P.dz[r]};
-        d3 p = o + d * c.t;                        // point = pos + dir * t
-        f3 nn = hit_normal(S, c.g, p, P.word[r]);
-        h0 = make_float4((float)c.t, __int_as_float(c.g), (float)p.x, (float)p.y);
-        h1 = make_float4((float)p.z, nn.x, nn.y, nn.z);
+    for (int k = 0; k < NS; ++k) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (!valid[r]) continue;
+        const uint32_t i = base + r * stride;
+        Closest c = ray_epilogue(S, P.ox[r], P.oy[r], P.oz[r], P.dx[r], P.dy[r], P.dz[r], P.word[k][r], P.c[k][r],
+                                 pre[k][r], stats);
+        float4 h0 = make_float4(__builtin_inff(), __int_as_float(-1), 0.f, 0.f);
+        float4 h1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c.g >= 0) {
+          d3 o = d3{(double)P.ox[r], (double)P.oy[r], (double)P.oz[r]};
+          d3 d = d3{(double)P.dx[r], (double)P.dy[r], (double)P.dz[r]};
+          d3 p = o + d * c.t;                        // point = pos + dir * t
+          f3 nn = hit_normal(S, c.g, p, P.word[k][r]);
+          h0 = make_float4((float)c.t, __int_as_float(c.g), (float)p.x, (float)p.y);
+          h1 = make_float4((float)p.z, nn.x, nn.y, nn.z);
+        }
+        if (k == 0) { out0.h0[i] = h0; out0.h1[i] = h1; }
+        else        { out1.h0[i] = h0; out1.h1[i] = h1; }
       }
-      out.h0[i] = h0;
-      out.h1[i] = h1;
     }
   }
 }

@@ -28,8 +28,7 @@ struct SceneDev {
   const float4* sphF;     // static, non-precise spheres: (cx, cy, cz, r^2)
   const int* sphF_gid;    // -> global prim id
   int n_sphF;
-  const float4* msphF;    // moving spheres: (cx, cy, cz, r^2) at time 0
-  const float4* msphMv;   // (mvx, mvy, mvz, 0)
+  const float4* msphF;    // moving spheres, 2 float4 each: (cx, cy, cz, r^2) at time 0, (mvx, mvy, mvz, object id bits)
   const int* msph_gid;
   int n_msph;
   const int* prec_gid;    // "precise" spheres (|r| >= precise_radius): exact f64 test for every ray
@@ -37,7 +36,7 @@ struct SceneDev {
   const float4* triF;     // static triangles, 3 float4 each: (p0, -), (e1, -), (e2, -)
   const int* triF_gid;
   int n_triF;
-  const float4* mtriF;    // moving triangles, 4 float4 each: p0, e1, e2, mv
+  const float4* mtriF;    // moving triangles, 4 float4 each: p0, e1, e2, (mv, object id bits)
   const int* mtri_gid;
   int n_mtri;
   // ---- f64 master copies (exact evaluation) ----
@@ -58,6 +57,7 @@ struct SceneDev {
   const double* lsphD;    // light-shape spheres, 4 each
   const double* ltriD;    // light-shape triangles, 9 each
   int any_motion;
+  int prec_motion;        // some precise sphere moves
   int n_phong_mats;
   // ---- f32 error model of the cull, set by cftrt_scene_commit ----
   float K1, K2;            // |disc - true disc| <= K1*|q| + K2
