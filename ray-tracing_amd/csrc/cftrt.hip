@@ -293,7 +293,16 @@ int cftrt_scene_commit(cftrt_scene* s) {
     if (s->tri_mat[i] >= nm) return fail(ctx, CFTRT_ERR_INVALID, "triangle mat_id beyond the material table");
 
   std::vector<float4> sphF, msphF, triF, mtriF;
+  std::vector<float> sphR2;
   int prec_motion = 0;
+  // scene centre: bbox centre of every non-precise primitive; the f32 lists are stored relative to it
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  auto grow = [&](const double* p) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); } };
+  for (int i = 0; i < ns; ++i) if (std::fabs(s->sph_r[i]) < s->precise_radius) grow(&s->sph_c[3 * i]);
+  for (int i = 0; i < nt; ++i) { grow(&s->tri_p[9 * i]); grow(&s->tri_p[9 * i + 3]); grow(&s->tri_p[9 * i + 6]); }
+  float bcf[3] = {0.f, 0.f, 0.f};
+  if (lo[0] <= hi[0]) for (int k = 0; k < 3; ++k) bcf[k] = (float)(0.5 * (lo[k] + hi[k]));
+  const double bc[3] = {(double)bcf[0], (double)bcf[1], (double)bcf[2]};
   std::vector<int> sphF_gid, msph_gid, prec_gid, triF_gid, mtri_gid, prim_obj(ns + nt), prim_mat(ns + nt);
   std::vector<double> sphD(4 * (size_t)ns);
   int any_motion = 0;
@@ -312,11 +321,14 @@ int cftrt_scene_commit(cftrt_scene* s) {
     } else if (moving) {
       float objbits;
       memcpy(&objbits, &s->sph_obj[i], 4);
-      msphF.push_back(make_float4((float)c[0], (float)c[1], (float)c[2], (float)(r * r)));
+      msphF.push_back(make_float4((float)(c[0] - bc[0]), (float)(c[1] - bc[1]), (float)(c[2] - bc[2]), (float)(r * r)));
       msphF.push_back(make_float4((float)mv[0], (float)mv[1], (float)mv[2], objbits));
       msph_gid.push_back(i);
     } else {
-      sphF.push_back(make_float4((float)c[0], (float)c[1], (float)c[2], (float)(r * r)));
+      const double cx = c[0] - bc[0], cy = c[1] - bc[1], cz = c[2] - bc[2];
+      sphF.push_back(make_float4((float)(-2. * cx), (float)(-2. * cy), (float)(-2. * cz),
+                                 (float)(4. * (cx * cx + cy * cy + cz * cz - r * r))));
+      sphR2.push_back((float)(r * r));
       sphF_gid.push_back(i);
     }
   }
@@ -326,7 +338,7 @@ int cftrt_scene_commit(cftrt_scene* s) {
     prim_obj[ns + i] = s->tri_obj[i];
     prim_mat[ns + i] = s->tri_mat[i];
     bool moving = mv[0] != 0. || mv[1] != 0. || mv[2] != 0.;
-    float4 P0 = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f);
+    float4 P0 = make_float4((float)(p[0] - bc[0]), (float)(p[1] - bc[1]), (float)(p[2] - bc[2]), 0.f);
     float4 E1 = make_float4((float)(p[3] - p[0]), (float)(p[4] - p[1]), (float)(p[5] - p[2]), 0.f);
     float4 E2 = make_float4((float)(p[6] - p[0]), (float)(p[7] - p[1]), (float)(p[8] - p[2]), 0.f);
     if (moving) {
@@ -344,8 +356,8 @@ int cftrt_scene_commit(cftrt_scene* s) {
   msphF.push_back(make_float4(0.f, 0.f, 0.f, -1e30f));   // the prefetched extra entry of the moving list
   msphF.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
   const int n_sphF_real = (int)sphF_gid.size();
-  while (sphF.size() % 4) sphF.push_back(make_float4(0.f, 0.f, 0.f, -1e30f));   // never hit: disc = -1e30 - |l|^2
-  for (int k = 0; k < 4; ++k) sphF.push_back(make_float4(0.f, 0.f, 0.f, -1e30f));   // the prefetched extra batch
+  while (sphF.size() % 4) { sphF.push_back(make_float4(0.f, 0.f, 0.f, 1e30f)); sphR2.push_back(0.f); }   // never hit: 4 disc' = Q^2 - 1e30
+  for (int k = 0; k < 4; ++k) { sphF.push_back(make_float4(0.f, 0.f, 0.f, 1e30f)); sphR2.push_back(0.f); }   // the prefetched extra batch
   std::vector<MatDev> mats(nm);
   int n_phong = 0;
   for (int i = 0; i < nm; ++i) {
@@ -365,6 +377,7 @@ int cftrt_scene_commit(cftrt_scene* s) {
   int rc;
   if ((rc = upload(s, sphF, &D.sphF))) return rc;
   if ((rc = upload(s, sphF_gid, &D.sphF_gid))) return rc;
+  if ((rc = upload(s, sphR2, &D.sphR2))) return rc;
   if ((rc = upload(s, msphF, &D.msphF))) return rc;
   if ((rc = upload(s, msph_gid, &D.msph_gid))) return rc;
   if ((rc = upload(s, prec_gid, &D.prec_gid))) return rc;
@@ -398,31 +411,23 @@ int cftrt_scene_commit(cftrt_scene* s) {
     // f32 error model of the cull.  eps = 2^-24 (unit roundoff); every constant carries
     // a factor >= 2 over the bound derived there.
     const double eps = 5.9604644775390625e-8;
-    double rmax = 0., cmax = 0., bc[3] = {0., 0., 0.};
-    int nf = 0;
+    double rmax = 0., brad = 0.;
     for (int i = 0; i < ns; ++i) {
       if (std::fabs(s->sph_r[i]) >= s->precise_radius) continue;
       const double* c = &s->sph_c[3 * i];
       const double* mv = &s->sph_mv[3 * i];
       rmax = std::max(rmax, std::fabs(s->sph_r[i]));
-      cmax = std::max(cmax, std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) + std::sqrt(mv[0] * mv[0] + mv[1] * mv[1] + mv[2] * mv[2]));
-      bc[0] += c[0]; bc[1] += c[1]; bc[2] += c[2];
-      ++nf;
-    }
-    if (nf) { bc[0] /= nf; bc[1] /= nf; bc[2] /= nf; }
-    double brad = 0.;
-    for (int i = 0; i < ns; ++i) {
-      if (std::fabs(s->sph_r[i]) >= s->precise_radius) continue;
-      const double* c = &s->sph_c[3 * i];
-      const double* mv = &s->sph_mv[3 * i];
       double dx = c[0] - bc[0], dy = c[1] - bc[1], dz = c[2] - bc[2];
       brad = std::max(brad, std::sqrt(dx * dx + dy * dy + dz * dz) + std::sqrt(mv[0] * mv[0] + mv[1] * mv[1] + mv[2] * mv[2]));
     }
-    D.K1 = (float)(32. * eps * rmax);
-    D.K2 = (float)(eps * rmax * (48. * rmax + 16. * cmax));
-    D.K3 = (float)(8. * eps);
-    D.K4 = (float)(eps * (16. * rmax + 4. * cmax));
-    D.bcx = (float)bc[0]; D.bcy = (float)bc[1]; D.bcz = (float)bc[2];
+    const double cmax = brad;   // largest |c'| of the f32 lists
+    D.K1 = (float)(48. * eps * rmax);
+    D.K2 = (float)(eps * rmax * (72. * rmax + 24. * cmax));
+    D.K3 = (float)(12. * eps);
+    D.K4 = (float)(eps * (24. * rmax + 6. * cmax));
+    D.Kc = (float)(36. * eps);
+    D.rmax2 = (float)(rmax * rmax);
+    D.bcx = bcf[0]; D.bcy = bcf[1]; D.bcz = bcf[2];
     D.brad = (float)(brad * 1.000001 + 1e-6);
     double emax = 0., pmax = 0.;
     for (int i = 0; i < nt; ++i) {
@@ -431,7 +436,8 @@ int cftrt_scene_commit(cftrt_scene* s) {
       double e1 = std::sqrt((p[3] - p[0]) * (p[3] - p[0]) + (p[4] - p[1]) * (p[4] - p[1]) + (p[5] - p[2]) * (p[5] - p[2]));
       double e2 = std::sqrt((p[6] - p[0]) * (p[6] - p[0]) + (p[7] - p[1]) * (p[7] - p[1]) + (p[8] - p[2]) * (p[8] - p[2]));
       emax = std::max(emax, std::max(e1, e2));
-      pmax = std::max(pmax, std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) + std::sqrt(mv[0] * mv[0] + mv[1] * mv[1] + mv[2] * mv[2]));
+      double qx = p[0] - bc[0], qy = p[1] - bc[1], qz = p[2] - bc[2];
+      pmax = std::max(pmax, std::sqrt(qx * qx + qy * qy + qz * qz) + std::sqrt(mv[0] * mv[0] + mv[1] * mv[1] + mv[2] * mv[2]));
     }
     D.tKA = (float)(32. * eps * emax * emax);
     D.tKU1 = (float)(32. * eps * emax);

@@ -244,34 +244,53 @@ struct Closest {
 // static primitives are tested once and feed both candidate sets, moving ones are tested per scan.
 template <int R, int NS>
 struct RayPack {
-  float ox[R], oy[R], oz[R], dx[R], dy[R], dz[R];
-  float negE[R];          // -(fast-path margin) of the ray: candidates have disc >= negE
-  float U[R];             // upper bound on the winner's distance (exact precise-sphere hit), f32 rounded up
-  uint32_t word[NS][R];   // motion key of each scan
+  float ox[R], oy[R], oz[R];      // origin as given (the exact evaluation uses it)
+  float tx[R], ty[R], tz[R];      // origin relative to the scene centre S.bc (all f32 lists are stored relative to it)
+  float dx[R], dy[R], dz[R];
+  float o4x[R], o4y[R], o4z[R];   // 4 * t
+  float od2[R];                   // 2 * (t . d)
+  float thr4[R];                  // fast-path threshold: candidates have 4*disc' >= thr4 (cheap form)
+  float negE[R];                  // -(margin) of the robust discriminant: candidates have disc >= negE
+  float U[R];                     // upper bound on the winner's distance (exact precise-sphere hit), f32 rounded up
+  uint32_t word[NS][R];           // motion key of each scan
   Cand c[NS][R];
 };
 
+typedef const float __attribute__((address_space(4))) * c_f32p;
+
+// One static sphere against R rays.  The list stores C = -2 c' and k4 = 4 (|c'|^2 - r^2) (c' relative to the
+// scene centre), the ray carries o4 = 4 o', od2 = 2 o'.d, so with Q = 2 q = od2 + C.d and
+// cc4 = k4 + C.o4 = 4 (|c'|^2 - r^2 - 2 o'.c'):   4 disc = Q^2 - cc4 - 4 |o'|^2.
+// 7 FMA + 1 compare per ray on the common path; |o'|^2 and the error margin live in the per-ray threshold.
+// Lanes that pass recompute the cancellation-free form (q, disc = r^2 - |oc - q d|^2) for the tight bound.
 template <int R, int NS>
-__device__ __forceinline__ void scan_sphere(const SceneDev& S, RayPack<R, NS>& P, float negEmin, float cx, float cy,
-                                            float cz, float r2, int idx) {
-  float q[R], d[R];
-  float m = -__builtin_inff();
+__device__ __forceinline__ void scan_sphere(const SceneDev& S, RayPack<R, NS>& P, float Cx, float Cy, float Cz,
+                                            float k4, int idx) {
+  float D[R];
+  bool any = false;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    float ocx = P.ox[r] - cx, ocy = P.oy[r] - cy, ocz = P.oz[r] - cz;
-    q[r] = fmaf(ocz, P.dz[r], fmaf(ocy, P.dy[r], ocx * P.dx[r]));
-    float lx = fmaf(-q[r], P.dx[r], ocx), ly = fmaf(-q[r], P.dy[r], ocy), lz = fmaf(-q[r], P.dz[r], ocz);
-    d[r] = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, r2)));
-    m = fmaxf(m, d[r]);
+    float Q = fmaf(Cx, P.dx[r], fmaf(Cy, P.dy[r], fmaf(Cz, P.dz[r], P.od2[r])));
+    float cc = fmaf(Cx, P.o4x[r], fmaf(Cy, P.o4y[r], fmaf(Cz, P.o4z[r], k4)));
+    D[r] = fmaf(Q, Q, -cc);
+    any = any || (D[r] >= P.thr4[r]);
   }
-  if (__ballot(m >= negEmin) != 0ull) {
+  if (__ballot(any) != 0ull) {
+    const float r2 = AS_CONST(c_f32p, S.sphR2)[idx];
+    const float cx = -0.5f * Cx, cy = -0.5f * Cy, cz = -0.5f * Cz;
 #pragma unroll
     for (int r = 0; r < R; ++r)
-      if (d[r] >= P.negE[r]) {
-        float tlo = sphere_lower_bound(S, q[r], d[r], P.U[r]);
-        if (tlo >= 0.0f) {
+      if (D[r] >= P.thr4[r]) {
+        float ocx = P.tx[r] - cx, ocy = P.ty[r] - cy, ocz = P.tz[r] - cz;
+        float q = fmaf(ocz, P.dz[r], fmaf(ocy, P.dy[r], ocx * P.dx[r]));
+        float lx = fmaf(-q, P.dx[r], ocx), ly = fmaf(-q, P.dy[r], ocy), lz = fmaf(-q, P.dz[r], ocz);
+        float d = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, r2)));
+        if (d >= P.negE[r]) {
+          float tlo = sphere_lower_bound(S, q, d, P.U[r]);
+          if (tlo >= 0.0f) {
 #pragma unroll
-          for (int k = 0; k < NS; ++k) cand_insert(P.c[k][r], tlo, idx);
+            for (int k = 0; k < NS; ++k) cand_insert(P.c[k][r], tlo, idx);
+          }
         }
       }
   }
@@ -283,22 +302,19 @@ typedef const v8f __attribute__((address_space(4))) * c_f8p;
 // f32 scan of every non-precise primitive for R rays (indices into [sphF | msph | triF | mtri]).
 template <int R, int NS>
 __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P) {
-  float negEmin = P.negE[0];
-#pragma unroll
-  for (int r = 1; r < R; ++r) negEmin = fminf(negEmin, P.negE[r]);
   {
     // 4 spheres per s_load_dwordx16, fetched one batch ahead; the array is padded on the host with
-    // never-hit spheres (r^2 = -1e30) to a multiple of 4 plus one extra batch.
+    // never-hit spheres (k4 = +1e30) to a multiple of 4 plus one extra batch.
     c_f16p sp = AS_CONST(c_f16p, S.sphF);
     const int n4 = (S.n_sphF + 3) >> 2;
     v16f cur = sp[0];
     for (int s4 = 0; s4 < n4; ++s4) {
       v16f nxt = sp[s4 + 1];
       const int s = s4 << 2;
-      scan_sphere<R, NS>(S, P, negEmin, cur[0], cur[1], cur[2], cur[3], s);
-      scan_sphere<R, NS>(S, P, negEmin, cur[4], cur[5], cur[6], cur[7], s + 1);
-      scan_sphere<R, NS>(S, P, negEmin, cur[8], cur[9], cur[10], cur[11], s + 2);
-      scan_sphere<R, NS>(S, P, negEmin, cur[12], cur[13], cur[14], cur[15], s + 3);
+      scan_sphere<R, NS>(S, P, cur[0], cur[1], cur[2], cur[3], s);
+      scan_sphere<R, NS>(S, P, cur[4], cur[5], cur[6], cur[7], s + 1);
+      scan_sphere<R, NS>(S, P, cur[8], cur[9], cur[10], cur[11], s + 2);
+      scan_sphere<R, NS>(S, P, cur[12], cur[13], cur[14], cur[15], s + 3);
       cur = nxt;
     }
   }
@@ -318,7 +334,7 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P)
         for (int r = 0; r < R; ++r) {
           float tm = motion_time(P.word[k][r], obj);
           float cx = fmaf(cur[4], tm, cur[0]), cy = fmaf(cur[5], tm, cur[1]), cz = fmaf(cur[6], tm, cur[2]);
-          float ocx = P.ox[r] - cx, ocy = P.oy[r] - cy, ocz = P.oz[r] - cz;
+          float ocx = P.tx[r] - cx, ocy = P.ty[r] - cy, ocz = P.tz[r] - cz;
           float q = fmaf(ocz, P.dz[r], fmaf(ocy, P.dy[r], ocx * P.dx[r]));
           float lx = fmaf(-q, P.dx[r], ocx), ly = fmaf(-q, P.dy[r], ocy), lz = fmaf(-q, P.dz[r], ocz);
           float d = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, cur[3])));
@@ -339,7 +355,7 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P)
       v4f a = tp[3 * s], b = tp[3 * s + 1], cc = tp[3 * s + 2];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        float tlo = tri_lower_bound(S, P.ox[r], P.oy[r], P.oz[r], P.dx[r], P.dy[r], P.dz[r], mk3(a.x, a.y, a.z),
+        float tlo = tri_lower_bound(S, P.tx[r], P.ty[r], P.tz[r], P.dx[r], P.dy[r], P.dz[r], mk3(a.x, a.y, a.z),
                                     mk3(b.x, b.y, b.z), mk3(cc.x, cc.y, cc.z), P.U[r]);
         if (tlo >= 0.0f) {
 #pragma unroll
@@ -359,7 +375,7 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P)
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           float tm = motion_time(P.word[k][r], obj);
-          float tlo = tri_lower_bound(S, P.ox[r], P.oy[r], P.oz[r], P.dx[r], P.dy[r], P.dz[r],
+          float tlo = tri_lower_bound(S, P.tx[r], P.ty[r], P.tz[r], P.dx[r], P.dy[r], P.dz[r],
                                       mk3(fmaf(m.x, tm, a.x), fmaf(m.y, tm, a.y), fmaf(m.z, tm, a.z)),
                                       mk3(b.x, b.y, b.z), mk3(cc.x, cc.y, cc.z), P.U[r]);
           if (tlo >= 0.0f) cand_insert(P.c[k][r], tlo, base + s);
@@ -376,9 +392,9 @@ __device__ __forceinline__ int list_to_gid(const SceneDev& S, int i) {
   return S.mtri_gid[i - S.n_triF];
 }
 
-// Before the scan: the precise spheres, exactly; sets the ray's margins and upper bound.
-__device__ __forceinline__ Closest ray_prologue(const SceneDev& S, float ox, float oy, float oz, float dx, float dy,
-                                                float dz, uint32_t word, float* negE, float* U) {
+// Exact (f64) closest hit among the precise spheres.
+__device__ __forceinline__ Closest precise_hit(const SceneDev& S, float ox, float oy, float oz, float dx, float dy,
+                                               float dz, uint32_t word) {
   d3 o = d3{(double)ox, (double)oy, (double)oz};
   d3 d = d3{(double)dx, (double)dy, (double)dz};
   Closest r;
@@ -391,13 +407,27 @@ __device__ __forceinline__ Closest ray_prologue(const SceneDev& S, float ox, flo
       if (t < r.t || (t == r.t && S.prim_obj[g] < S.prim_obj[r.g])) { r.t = t; r.g = g; }
     }
   }
-  // |q| <= |oc| <= dist(origin, bounding sphere centre of the f32 sphere list) + its radius
-  float bx = ox - S.bcx, by = oy - S.bcy, bz = oz - S.bcz;
-  float dist = sqrtf(fmaf(bz, bz, fmaf(by, by, bx * bx))) * 1.000001f + S.brad;
-  *negE = -fmaf(dist, S.K1, S.K2);
-  float u = (float)r.t;                      // round to nearest, then push up past the f64 value
-  *U = (r.g >= 0) ? fmaf(fabsf(u), CFT_U4EPS, u) + 1e-30f : __builtin_inff();
   return r;
+}
+
+// Before the scan: slot r of the pack (translated origin, scaled copies, margins, upper bound).
+template <int R, int NS>
+__device__ __forceinline__ void ray_setup(const SceneDev& S, RayPack<R, NS>& P, int r, float ox, float oy, float oz,
+                                          float dx, float dy, float dz, const Closest& pre) {
+  P.ox[r] = ox; P.oy[r] = oy; P.oz[r] = oz; P.dx[r] = dx; P.dy[r] = dy; P.dz[r] = dz;
+  const float tx = ox - S.bcx, ty = oy - S.bcy, tz = oz - S.bcz;
+  P.tx[r] = tx; P.ty[r] = ty; P.tz[r] = tz;
+  P.o4x[r] = 4.0f * tx; P.o4y[r] = 4.0f * ty; P.o4z[r] = 4.0f * tz;
+  P.od2[r] = 2.0f * fmaf(tz, dz, fmaf(ty, dy, tx * dx));
+  const float oo = fmaf(tz, tz, fmaf(ty, ty, tx * tx));
+  // |o'| + |c'| <= dist: bound of every magnitude in the scan (S.brad = largest |c'| incl. motion)
+  const float dist = sqrtf(oo) * 1.000001f + S.brad;
+  P.negE[r] = -fmaf(dist, S.K1, S.K2);
+  // cheap form: |4 disc' - 4 oo - 4 disc*| <= 4 Kc (dist^2 + rmax^2)  =>  pass iff  4 disc' >= 4 (oo - E)
+  const float thr = fmaf(-S.Kc, fmaf(dist, dist, S.rmax2), oo);
+  P.thr4[r] = 4.0f * (thr - fabsf(thr) * CFT_U4EPS) - 1e-30f;
+  const float u = (float)pre.t;              // round to nearest, then push up past the f64 value
+  P.U[r] = (pre.g >= 0) ? fmaf(fabsf(u), CFT_U4EPS, u) + 1e-30f : __builtin_inff();
 }
 
 // After the scan: exact evaluation of the two best candidates, rescan if a third could still win.
@@ -438,12 +468,12 @@ __device__ __forceinline__ Closest ray_epilogue(const SceneDev& S, float ox, flo
 __device__ __forceinline__ Closest closest_hit(const SceneDev& S, float ox, float oy, float oz, float dx,
                                                float dy, float dz, uint32_t scan_word, uint32_t* stats) {
   RayPack<1, 1> P;
-  P.ox[0] = ox; P.oy[0] = oy; P.oz[0] = oz; P.dx[0] = dx; P.dy[0] = dy; P.dz[0] = dz;
   P.word[0][0] = scan_word;
   cand_init(P.c[0][0]);
-  Closest r = ray_prologue(S, ox, oy, oz, dx, dy, dz, scan_word, &P.negE[0], &P.U[0]);
+  Closest pre = precise_hit(S, ox, oy, oz, dx, dy, dz, scan_word);
+  ray_setup<1, 1>(S, P, 0, ox, oy, oz, dx, dy, dz, pre);
   scan_lists<1, 1>(S, P);
-  return ray_epilogue(S, ox, oy, oz, dx, dy, dz, scan_word, P.c[0][0], r, stats);
+  return ray_epilogue(S, ox, oy, oz, dx, dy, dz, scan_word, P.c[0][0], pre, stats);
 }
 
 // ------------------------------------------------------------------ generate
@@ -536,8 +566,7 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_intersect(SceneDev S, QueueDev q,
     for (int r = 0; r < R; ++r) {
       const uint32_t i = base + r * stride;
       valid[r] = i < n;
-      P.ox[r] = 0.f; P.oy[r] = 0.f; P.oz[r] = 0.f; P.dx[r] = 0.f; P.dy[r] = 0.f; P.dz[r] = 1.f;
-      P.negE[r] = __builtin_inff(); P.U[r] = 0.f;
+      float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 1.f;
 #pragma unroll
       for (int k = 0; k < NS; ++k) {
         P.word[k][r] = 0;
@@ -547,7 +576,7 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_intersect(SceneDev S, QueueDev q,
       if (valid[r]) {
         float4 a = q.a[i];
         float4 b = q.b[i];
-        P.ox[r] = a.x; P.oy[r] = a.y; P.oz[r] = a.z; P.dx[r] = a.w; P.dy[r] = b.x; P.dz[r] = b.y;
+        ox = a.x; oy = a.y; oz = a.z; dx = a.w; dy = b.x; dz = b.y;
         if (S.any_motion) {
           uint64_t pid = pid_base + __float_as_uint(q.c[i].y);
 #pragma unroll
@@ -555,16 +584,12 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_intersect(SceneDev S, QueueDev q,
             P.word[k][r] = philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), level,
                                          CFT_PURPOSE_SCAN0 + (k == 0 ? role0 : role1), k0, k1).x;
         }
-        pre[0][r] = ray_prologue(S, P.ox[r], P.oy[r], P.oz[r], P.dx[r], P.dy[r], P.dz[r], P.word[0][r], &P.negE[r], &P.U[r]);
-        if (NS == 2) {
-          pre[NS - 1][r] = pre[0][r];
-          if (S.prec_motion) {   // a moving precise sphere: its exact hit differs per scan; no shared bound
-            float ne, u;
-            pre[NS - 1][r] = ray_prologue(S, P.ox[r], P.oy[r], P.oz[r], P.dx[r], P.dy[r], P.dz[r], P.word[NS - 1][r], &ne, &u);
-            P.U[r] = __builtin_inff();
-          }
-        }
+        pre[0][r] = precise_hit(S, ox, oy, oz, dx, dy, dz, P.word[0][r]);
+        if (NS == 2) pre[NS - 1][r] = S.prec_motion ? precise_hit(S, ox, oy, oz, dx, dy, dz, P.word[NS - 1][r]) : pre[0][r];
       }
+      ray_setup<R, NS>(S, P, r, ox, oy, oz, dx, dy, dz, pre[0][r]);
+      if (!valid[r]) { P.thr4[r] = __builtin_inff(); P.negE[r] = __builtin_inff(); }   // a dummy slot never is a candidate
+      if (NS == 2 && S.prec_motion) P.U[r] = __builtin_inff();   // a moving precise sphere: no shared upper bound
     }
     scan_lists<R, NS>(S, P);
 #pragma unroll

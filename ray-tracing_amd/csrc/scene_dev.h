@@ -25,7 +25,8 @@ struct LightDev {  // device light list row
 // prim_obj[g] is the owning object's index in world.objects (the parity "object id").
 struct SceneDev {
   // ---- f32 cull lists (hot loops) ----
-  const float4* sphF;     // static, non-precise spheres: (cx, cy, cz, r^2)
+  const float4* sphF;     // static, non-precise spheres: (-2c'x, -2c'y, -2c'z, 4(|c'|^2 - r^2)), c' = c - bc
+  const float* sphR2;     // their r^2 (read by the candidate path only)
   const int* sphF_gid;    // -> global prim id
   int n_sphF;
   const float4* msphF;    // moving spheres, 2 float4 each: (cx, cy, cz, r^2) at time 0, (mvx, mvy, mvz, object id bits)
@@ -62,7 +63,8 @@ struct SceneDev {
   // ---- f32 error model of the cull, set by cftrt_scene_commit ----
   float K1, K2;            // |disc - true disc| <= K1*|q| + K2
   float K3, K4;            // |q - true q|       <= K3*|q| + K4
-  float bcx, bcy, bcz, brad;   // bounding sphere of the f32 sphere lists (centres + radii + motion)
+  float Kc, rmax2;         // cheap form: |disc' - true| <= Kc*((|o'| + brad)^2 + rmax^2)
+  float bcx, bcy, bcz, brad;   // scene centre bc (f32 lists are stored relative to it) and the largest |c'| (+ motion)
   float tKA;               // |a - true a| (triangle determinant)
   float tKU1, tKU2;        // |u,v - true| <= |f| * (tKU1*|s|_1 + tKU2)
   float tKT1, tKT2, tKT3;  // |t - true t| <= |f| * (tKT1*|s|_1 + tKT2 + tKT3*|t|)
