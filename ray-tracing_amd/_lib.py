@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libcftrt.so")
+LIB_PATH = os.environ.get("CFTRT_LIB") or os.path.join(_HERE, "csrc", "libcftrt.so")   # CFTRT_LIB: experiments only
 
 CFTRT_MAX_LEVELS = 256
 

@@ -328,7 +328,7 @@ int cftrt_scene_commit(cftrt_scene* s) {
       const double cx = c[0] - bc[0], cy = c[1] - bc[1], cz = c[2] - bc[2];
       sphF.push_back(make_float4((float)(-2. * cx), (float)(-2. * cy), (float)(-2. * cz),
                                  (float)(4. * (cx * cx + cy * cy + cz * cz - r * r))));
-      sphR2.push_back((float)(r * r));
+      sphR2.push_back(16.0f * (float)(r * r));   // the candidate path works on 16 disc (exact scaling)
       sphF_gid.push_back(i);
     }
   }
@@ -422,7 +422,7 @@ int cftrt_scene_commit(cftrt_scene* s) {
     }
     const double cmax = brad;   // largest |c'| of the f32 lists
     D.K1 = (float)(48. * eps * rmax);
-    D.K2 = (float)(eps * rmax * (72. * rmax + 24. * cmax));
+    D.K2 = (float)(eps * (rmax * (72. * rmax + 24. * cmax)));
     D.K3 = (float)(12. * eps);
     D.K4 = (float)(eps * (24. * rmax + 6. * cmax));
     D.Kc = (float)(36. * eps);

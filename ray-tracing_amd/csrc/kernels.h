@@ -20,7 +20,7 @@
 #define CFT_BLOCK 256
 #define CFT_SHADE_CHUNK 1024
 #ifndef CFT_RAYS_PER_LANE
-#define CFT_RAYS_PER_LANE 2
+#define CFT_RAYS_PER_LANE 4
 #endif
 
 // constant-address-space views: a wave-uniform index then compiles to s_load (SGPR operands)
@@ -173,12 +173,23 @@ __device__ __forceinline__ void cand_init(Cand& c) {
   c.i1 = c.i2 = -1;
 }
 __device__ __forceinline__ void cand_insert(Cand& c, float tlo, int idx) {
+#if 1
+  // straight-line: masks + bitfield selects (nested ?: compiles to nested exec-mask branches)
+  const int m1 = (tlo < c.lo1) ? -1 : 0, m2 = (tlo < c.lo2) ? -1 : 0;
+  c.lo3 = __builtin_amdgcn_fmed3f(c.lo2, c.lo3, tlo);
+  const int t2 = (m2 & idx) | (~m2 & c.i2);
+  c.i2 = (m1 & c.i1) | (~m1 & t2);
+  c.lo2 = __builtin_amdgcn_fmed3f(c.lo1, c.lo2, tlo);
+  c.i1 = (m1 & idx) | (~m1 & c.i1);
+  c.lo1 = fminf(c.lo1, tlo);
+#else
   const bool c1 = tlo < c.lo1, c2 = tlo < c.lo2;
   c.lo3 = __builtin_amdgcn_fmed3f(c.lo2, c.lo3, tlo);
   c.i2 = c1 ? c.i1 : (c2 ? idx : c.i2);
   c.lo2 = __builtin_amdgcn_fmed3f(c.lo1, c.lo2, tlo);
   c.i1 = c1 ? idx : c.i1;
   c.lo1 = fminf(c.lo1, tlo);
+#endif
 }
 
 #define CFT_U4EPS 2.3841858e-7f   // 4 * 2^-24: slack for a 1-ulp sqrt/rcp and the final adds
@@ -191,19 +202,15 @@ __device__ __forceinline__ float sphere_lower_bound(const SceneDev& S, float q, 
   const float e = fmaf(aq, S.K1, S.K2);                 // |disc - true disc| <= e
   const float eq = fmaf(aq, S.K3, S.K4);                // |q - true q| <= eq
   const bool inside = fmaf(-q, q, d) > e;               // r^2 - |oc|^2 = disc - q^2 certainly > 0
-  const float arg = inside ? fmaxf(d - e, 0.0f) : d + e;
-  float r = -1.0f;
-  if (arg >= 0.0f) {
-    const float s = __builtin_amdgcn_sqrtf(arg);
-    const float s_hi = fmaf(s, CFT_U4EPS, s), s_lo = fmaf(-s, CFT_U4EPS, s);
-    // outside: t = t1 = -q - sqrt(disc) >= -q - s_hi ; inside: t = t2 = -q + sqrt(disc) >= -q + s_lo
-    float tlo = inside ? (s_lo - q) : -(q + s_hi);
-    tlo = tlo - eq - fabsf(tlo) * CFT_U4EPS;
-    const bool possible = inside || (s_hi - q + eq >= 0.0f);   // t2 could be >= 0
-    tlo = fmaxf(tlo, 0.0f);
-    if (possible && tlo <= U) r = tlo;
-  }
-  return r;
+  const float arg = inside ? d - e : d + e;             // inside: disc > q^2 + e, so d - e > 0
+  const float s = __builtin_amdgcn_sqrtf(fmaxf(arg, 0.0f));
+  const float s_hi = fmaf(s, CFT_U4EPS, s), s_lo = fmaf(-s, CFT_U4EPS, s);
+  // outside: t = t1 = -q - sqrt(disc) >= -q - s_hi ; inside: t = t2 = -q + sqrt(disc) >= -q + s_lo
+  float tlo = inside ? (s_lo - q) : -(q + s_hi);
+  tlo = tlo - eq - fabsf(tlo) * CFT_U4EPS;
+  const bool possible = arg >= 0.0f && (inside || (s_hi - q + eq >= 0.0f));   // disc, t2 could be >= 0
+  tlo = fmaxf(tlo, 0.0f);
+  return (possible && tlo <= U) ? tlo : -1.0f;
 }
 
 // Moller-Trumbore in f32 with explicit error margins (triangle = p0, e1, e2): lower bound on the hit
@@ -242,51 +249,91 @@ struct Closest {
 // uniform branch per sphere serves all of them.  NS scans per ray: the reference scans the world up to
 // twice per trace level (the lights' `looked`, then trace's own Ray::hit), each with fresh motion times;
 // static primitives are tested once and feed both candidate sets, moving ones are tested per scan.
+//
+// Rays are held in PAIRS (slot r = element r&1 of pair r>>1) because the cull runs on v_pk_fma_f32: on
+// gfx950 one v_pk_fma_f32 (two FMAs) issues in ~1.5 slots, a v_fma_f32 with an SGPR source in ~1.46
+// (scripts/ubench_valu.hip), so the packed form is nearly twice as cheap per test.  An odd R leaves the
+// last slot a dummy (thr4 = +inf never passes).
+typedef float v2f __attribute__((ext_vector_type(2)));
 template <int R, int NS>
 struct RayPack {
-  float ox[R], oy[R], oz[R];      // origin as given (the exact evaluation uses it)
-  float tx[R], ty[R], tz[R];      // origin relative to the scene centre S.bc (all f32 lists are stored relative to it)
-  float dx[R], dy[R], dz[R];
-  float o4x[R], o4y[R], o4z[R];   // 4 * t
-  float od2[R];                   // 2 * (t . d)
-  float thr4[R];                  // fast-path threshold: candidates have 4*disc' >= thr4 (cheap form)
-  float negE[R];                  // -(margin) of the robust discriminant: candidates have disc >= negE
+  static constexpr int NP = (R + 1) / 2;
+  // Registers held across the scan are the occupancy limit of k_intersect, so the pack carries only what
+  // the scan reads: the origin as given is re-read from the ray queue by the epilogue, and the origin
+  // relative to the scene centre is kept only as o4 = 4 o' (scaling by 4 is exact).
+  v2f dx[NP], dy[NP], dz[NP];
+  v2f o4x[NP], o4y[NP], o4z[NP];  // 4 * o', o' = origin relative to the scene centre S.bc (all f32 lists are relative to it)
+  v2f od2[NP];                    // 2 * (o' . d)
+  v2f thr4[NP];                   // fast-path threshold 4 (|o'|^2 - margin), folded into the cull's o4 chain
+  float negE16[R];                // -16 * (margin of the robust discriminant): candidates have 16 disc >= negE16
   float U[R];                     // upper bound on the winner's distance (exact precise-sphere hit), f32 rounded up
   uint32_t word[NS][R];           // motion key of each scan
   Cand c[NS][R];
 };
+#define PK(P, f, r) ((P).f[(r) >> 1][(r) & 1])
+
+template <int R, int NS>
+__device__ __forceinline__ void pack_dummy_slot(RayPack<R, NS>& P, int r) {   // a slot that never is a candidate
+  PK(P, dx, r) = 0.f; PK(P, dy, r) = 0.f; PK(P, dz, r) = 1.f;
+  PK(P, o4x, r) = 0.f; PK(P, o4y, r) = 0.f; PK(P, o4z, r) = 0.f;
+  PK(P, od2, r) = 0.f;
+  PK(P, thr4, r) = __builtin_inff();
+}
 
 typedef const float __attribute__((address_space(4))) * c_f32p;
 
-// One static sphere against R rays.  The list stores C = -2 c' and k4 = 4 (|c'|^2 - r^2) (c' relative to the
-// scene centre), the ray carries o4 = 4 o', od2 = 2 o'.d, so with Q = 2 q = od2 + C.d and
-// cc4 = k4 + C.o4 = 4 (|c'|^2 - r^2 - 2 o'.c'):   4 disc = Q^2 - cc4 - 4 |o'|^2.
-// 7 FMA + 1 compare per ray on the common path; |o'|^2 and the error margin live in the per-ray threshold.
-// Lanes that pass recompute the cancellation-free form (q, disc = r^2 - |oc - q d|^2) for the tight bound.
+// The cull of one sphere against one ray pair, 7 v_pk_fma_f32.  The list stores C = -2 c' and
+// k4 = 4 (|c'|^2 - r^2) (c' relative to the scene centre) as the SGPR pairs (Cx, Cy), (Cz, k4); the ray carries
+// o4 = 4 o', od2 = 2 o'.d and thr4.  With Q = 2 q = od2 + C.d:
+//     V = Q^2 - (thr4 + C.o4)      and      4 disc = Q^2 - k4 - C.o4 - 4 |o'|^2 = V - k4 + (thr4 - 4 |o'|^2)
+// so "disc >= -margin" is "V >= k4" once thr4 = 4 (|o'|^2 - margin): the per-ray threshold rides in the
+// chain's start value and the compare is against a scalar, which lets ONE v_cmp serve all R rays (max of V).
+// The two chains are interleaved so that no instruction reads the result of the one before it.
+__device__ __forceinline__ v2f pair_cull(v2f cxy, v2f czk, v2f dx, v2f dy, v2f dz, v2f od2, v2f o4x, v2f o4y, v2f o4z,
+                                         v2f thr4) {
+  v2f q, c, v;
+  asm("v_pk_fma_f32 %0, %3, %7, %8 op_sel_hi:[0,1,1]\n\t"         // q  = Cz * dz + od2
+      "v_pk_fma_f32 %1, %3, %11, %12 op_sel_hi:[0,1,1]\n\t"       // c  = Cz * o4z + thr4
+      "v_pk_fma_f32 %0, %4, %6, %0 op_sel:[1,0,0]\n\t"            // q += Cy * dy
+      "v_pk_fma_f32 %1, %4, %10, %1 op_sel:[1,0,0]\n\t"           // c += Cy * o4y
+      "v_pk_fma_f32 %0, %4, %5, %0 op_sel_hi:[0,1,1]\n\t"         // q += Cx * dx
+      "v_pk_fma_f32 %1, %4, %9, %1 op_sel_hi:[0,1,1]\n\t"         // c += Cx * o4x
+      "v_pk_fma_f32 %2, %0, %0, %1 neg_lo:[0,0,1] neg_hi:[0,0,1]"   // v  = q * q - c
+      : "=&v"(q), "=&v"(c), "=&v"(v)
+      : "s"(czk), "s"(cxy), "v"(dx), "v"(dy), "v"(dz), "v"(od2), "v"(o4x), "v"(o4y), "v"(o4z), "v"(thr4));
+  return v;
+}
+
+// One static sphere against R rays: cull (above), then the lanes that pass recompute the cancellation-free
+// form (q, disc = r^2 - |oc - q d|^2) for the tight bound.
 template <int R, int NS>
-__device__ __forceinline__ void scan_sphere(const SceneDev& S, RayPack<R, NS>& P, float Cx, float Cy, float Cz,
-                                            float k4, int idx) {
-  float D[R];
-  bool any = false;
+__device__ __forceinline__ void scan_sphere(const SceneDev& S, RayPack<R, NS>& P, v2f cxy, v2f czk, float r2x16,
+                                            int idx) {
+  constexpr int NP = RayPack<R, NS>::NP;
+  v2f V[NP];
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    float Q = fmaf(Cx, P.dx[r], fmaf(Cy, P.dy[r], fmaf(Cz, P.dz[r], P.od2[r])));
-    float cc = fmaf(Cx, P.o4x[r], fmaf(Cy, P.o4y[r], fmaf(Cz, P.o4z[r], k4)));
-    D[r] = fmaf(Q, Q, -cc);
-    any = any || (D[r] >= P.thr4[r]);
-  }
-  if (__ballot(any) != 0ull) {
-    const float r2 = AS_CONST(c_f32p, S.sphR2)[idx];
-    const float cx = -0.5f * Cx, cy = -0.5f * Cy, cz = -0.5f * Cz;
+  for (int h = 0; h < NP; ++h)
+    V[h] = pair_cull(cxy, czk, P.dx[h], P.dy[h], P.dz[h], P.od2[h], P.o4x[h], P.o4y[h], P.o4z[h], P.thr4[h]);
+  // max over the slots: plain v_max / v_max3 (the values come out of FMAs; fmaxf would add canonicalising ops)
+  float m;
+  asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(V[0].x), "v"(V[0].y));
+#pragma unroll
+  for (int h = 1; h < NP; ++h) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(V[h].x), "v"(V[h].y));
+  const float k4 = czk.y;
+  if (__builtin_amdgcn_ballot_w64(m >= k4) != 0ull) {
+    const float Cx = cxy.x, Cy = cxy.y, Cz = czk.x;
 #pragma unroll
     for (int r = 0; r < R; ++r)
-      if (D[r] >= P.thr4[r]) {
-        float ocx = P.tx[r] - cx, ocy = P.ty[r] - cy, ocz = P.tz[r] - cz;
-        float q = fmaf(ocz, P.dz[r], fmaf(ocy, P.dy[r], ocx * P.dx[r]));
-        float lx = fmaf(-q, P.dx[r], ocx), ly = fmaf(-q, P.dy[r], ocy), lz = fmaf(-q, P.dz[r], ocz);
-        float d = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, r2)));
-        if (d >= P.negE[r]) {
-          float tlo = sphere_lower_bound(S, q, d, P.U[r]);
+      if (V[r >> 1][r & 1] >= k4) {
+        // everything scaled by 4 (16 for squares), which is exact: 4 oc = 4 o' + 2 C is one rounding of the same
+        // real number as 4 (o' - c'), so q4 = 4 q and d16 = 16 disc bit for bit
+        const float dx = PK(P, dx, r), dy = PK(P, dy, r), dz = PK(P, dz, r);
+        float ocx = fmaf(2.0f, Cx, PK(P, o4x, r)), ocy = fmaf(2.0f, Cy, PK(P, o4y, r)), ocz = fmaf(2.0f, Cz, PK(P, o4z, r));
+        float q4 = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
+        float lx = fmaf(-q4, dx, ocx), ly = fmaf(-q4, dy, ocy), lz = fmaf(-q4, dz, ocz);
+        float d16 = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, r2x16)));
+        if (d16 >= P.negE16[r]) {
+          float tlo = sphere_lower_bound(S, 0.25f * q4, 0.0625f * d16, P.U[r]);
           if (tlo >= 0.0f) {
 #pragma unroll
             for (int k = 0; k < NS; ++k) cand_insert(P.c[k][r], tlo, idx);
@@ -303,19 +350,23 @@ typedef const v8f __attribute__((address_space(4))) * c_f8p;
 template <int R, int NS>
 __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P) {
   {
-    // 4 spheres per s_load_dwordx16, fetched one batch ahead; the array is padded on the host with
-    // never-hit spheres (k4 = +1e30) to a multiple of 4 plus one extra batch.
+    // 4 spheres per s_load_dwordx16 (+ their r^2 in one s_load_dwordx4), fetched one batch ahead; both
+    // arrays are padded on the host with never-hit spheres (k4 = +1e30) to a multiple of 4 plus one batch.
     c_f16p sp = AS_CONST(c_f16p, S.sphF);
+    c_f4p rp = AS_CONST(c_f4p, S.sphR2);
     const int n4 = (S.n_sphF + 3) >> 2;
     v16f cur = sp[0];
+    v4f cr = rp[0];
     for (int s4 = 0; s4 < n4; ++s4) {
       v16f nxt = sp[s4 + 1];
+      v4f nr = rp[s4 + 1];
       const int s = s4 << 2;
-      scan_sphere<R, NS>(S, P, cur[0], cur[1], cur[2], cur[3], s);
-      scan_sphere<R, NS>(S, P, cur[4], cur[5], cur[6], cur[7], s + 1);
-      scan_sphere<R, NS>(S, P, cur[8], cur[9], cur[10], cur[11], s + 2);
-      scan_sphere<R, NS>(S, P, cur[12], cur[13], cur[14], cur[15], s + 3);
+      scan_sphere<R, NS>(S, P, v2f{cur[0], cur[1]}, v2f{cur[2], cur[3]}, cr[0], s);
+      scan_sphere<R, NS>(S, P, v2f{cur[4], cur[5]}, v2f{cur[6], cur[7]}, cr[1], s + 1);
+      scan_sphere<R, NS>(S, P, v2f{cur[8], cur[9]}, v2f{cur[10], cur[11]}, cr[2], s + 2);
+      scan_sphere<R, NS>(S, P, v2f{cur[12], cur[13]}, v2f{cur[14], cur[15]}, cr[3], s + 3);
       cur = nxt;
+      cr = nr;
     }
   }
   int base = S.n_sphF;
@@ -334,11 +385,12 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P)
         for (int r = 0; r < R; ++r) {
           float tm = motion_time(P.word[k][r], obj);
           float cx = fmaf(cur[4], tm, cur[0]), cy = fmaf(cur[5], tm, cur[1]), cz = fmaf(cur[6], tm, cur[2]);
-          float ocx = P.tx[r] - cx, ocy = P.ty[r] - cy, ocz = P.tz[r] - cz;
-          float q = fmaf(ocz, P.dz[r], fmaf(ocy, P.dy[r], ocx * P.dx[r]));
-          float lx = fmaf(-q, P.dx[r], ocx), ly = fmaf(-q, P.dy[r], ocy), lz = fmaf(-q, P.dz[r], ocz);
+          const float dx = PK(P, dx, r), dy = PK(P, dy, r), dz = PK(P, dz, r);
+          float ocx = fmaf(0.25f, PK(P, o4x, r), -cx), ocy = fmaf(0.25f, PK(P, o4y, r), -cy), ocz = fmaf(0.25f, PK(P, o4z, r), -cz);
+          float q = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
+          float lx = fmaf(-q, dx, ocx), ly = fmaf(-q, dy, ocy), lz = fmaf(-q, dz, ocz);
           float d = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, cur[3])));
-          if (d >= P.negE[r]) {
+          if (16.0f * d >= P.negE16[r]) {
             float tlo = sphere_lower_bound(S, q, d, P.U[r]);
             if (tlo >= 0.0f) cand_insert(P.c[k][r], tlo, base + s);
           }
@@ -355,8 +407,9 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P)
       v4f a = tp[3 * s], b = tp[3 * s + 1], cc = tp[3 * s + 2];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        float tlo = tri_lower_bound(S, P.tx[r], P.ty[r], P.tz[r], P.dx[r], P.dy[r], P.dz[r], mk3(a.x, a.y, a.z),
-                                    mk3(b.x, b.y, b.z), mk3(cc.x, cc.y, cc.z), P.U[r]);
+        float tlo = tri_lower_bound(S, 0.25f * PK(P, o4x, r), 0.25f * PK(P, o4y, r), 0.25f * PK(P, o4z, r), PK(P, dx, r),
+                                    PK(P, dy, r), PK(P, dz, r), mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z),
+                                    mk3(cc.x, cc.y, cc.z), P.U[r]);
         if (tlo >= 0.0f) {
 #pragma unroll
           for (int k = 0; k < NS; ++k) cand_insert(P.c[k][r], tlo, base + s);
@@ -375,7 +428,8 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P)
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           float tm = motion_time(P.word[k][r], obj);
-          float tlo = tri_lower_bound(S, P.tx[r], P.ty[r], P.tz[r], P.dx[r], P.dy[r], P.dz[r],
+          float tlo = tri_lower_bound(S, 0.25f * PK(P, o4x, r), 0.25f * PK(P, o4y, r), 0.25f * PK(P, o4z, r), PK(P, dx, r),
+                                      PK(P, dy, r), PK(P, dz, r),
                                       mk3(fmaf(m.x, tm, a.x), fmaf(m.y, tm, a.y), fmaf(m.z, tm, a.z)),
                                       mk3(b.x, b.y, b.z), mk3(cc.x, cc.y, cc.z), P.U[r]);
           if (tlo >= 0.0f) cand_insert(P.c[k][r], tlo, base + s);
@@ -414,18 +468,17 @@ __device__ __forceinline__ Closest precise_hit(const SceneDev& S, float ox, floa
 template <int R, int NS>
 __device__ __forceinline__ void ray_setup(const SceneDev& S, RayPack<R, NS>& P, int r, float ox, float oy, float oz,
                                           float dx, float dy, float dz, const Closest& pre) {
-  P.ox[r] = ox; P.oy[r] = oy; P.oz[r] = oz; P.dx[r] = dx; P.dy[r] = dy; P.dz[r] = dz;
+  PK(P, dx, r) = dx; PK(P, dy, r) = dy; PK(P, dz, r) = dz;
   const float tx = ox - S.bcx, ty = oy - S.bcy, tz = oz - S.bcz;
-  P.tx[r] = tx; P.ty[r] = ty; P.tz[r] = tz;
-  P.o4x[r] = 4.0f * tx; P.o4y[r] = 4.0f * ty; P.o4z[r] = 4.0f * tz;
-  P.od2[r] = 2.0f * fmaf(tz, dz, fmaf(ty, dy, tx * dx));
+  PK(P, o4x, r) = 4.0f * tx; PK(P, o4y, r) = 4.0f * ty; PK(P, o4z, r) = 4.0f * tz;
+  PK(P, od2, r) = 2.0f * fmaf(tz, dz, fmaf(ty, dy, tx * dx));
   const float oo = fmaf(tz, tz, fmaf(ty, ty, tx * tx));
   // |o'| + |c'| <= dist: bound of every magnitude in the scan (S.brad = largest |c'| incl. motion)
   const float dist = sqrtf(oo) * 1.000001f + S.brad;
-  P.negE[r] = -fmaf(dist, S.K1, S.K2);
+  P.negE16[r] = -16.0f * fmaf(dist, S.K1, S.K2);
   // cheap form: |4 disc' - 4 oo - 4 disc*| <= 4 Kc (dist^2 + rmax^2)  =>  pass iff  4 disc' >= 4 (oo - E)
   const float thr = fmaf(-S.Kc, fmaf(dist, dist, S.rmax2), oo);
-  P.thr4[r] = 4.0f * (thr - fabsf(thr) * CFT_U4EPS) - 1e-30f;
+  PK(P, thr4, r) = 4.0f * (thr - fabsf(thr) * CFT_U4EPS) - 1e-30f;
   const float u = (float)pre.t;              // round to nearest, then push up past the f64 value
   P.U[r] = (pre.g >= 0) ? fmaf(fabsf(u), CFT_U4EPS, u) + 1e-30f : __builtin_inff();
 }
@@ -472,6 +525,7 @@ __device__ __forceinline__ Closest closest_hit(const SceneDev& S, float ox, floa
   cand_init(P.c[0][0]);
   Closest pre = precise_hit(S, ox, oy, oz, dx, dy, dz, scan_word);
   ray_setup<1, 1>(S, P, 0, ox, oy, oz, dx, dy, dz, pre);
+  pack_dummy_slot<1, 1>(P, 1);
   scan_lists<1, 1>(S, P);
   return ray_epilogue(S, ox, oy, oz, dx, dy, dz, scan_word, P.c[0][0], pre, stats);
 }
@@ -560,20 +614,18 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_intersect(SceneDev S, QueueDev q,
   const uint32_t stride = gridDim.x * CFT_BLOCK;
   for (uint32_t base = blockIdx.x * CFT_BLOCK + threadIdx.x; base < n; base += stride * R) {
     RayPack<R, NS> P;
-    Closest pre[NS][R];
-    bool valid[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const uint32_t i = base + r * stride;
-      valid[r] = i < n;
       float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 1.f;
+      Closest pre;
+      pre.t = __builtin_inf(); pre.g = -1;
 #pragma unroll
       for (int k = 0; k < NS; ++k) {
         P.word[k][r] = 0;
-        pre[k][r].t = __builtin_inf(); pre[k][r].g = -1;
         cand_init(P.c[k][r]);
       }
-      if (valid[r]) {
+      if (i < n) {
         float4 a = q.a[i];
         float4 b = q.b[i];
         ox = a.x; oy = a.y; oz = a.z; dx = a.w; dy = b.x; dz = b.y;
@@ -584,27 +636,30 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_intersect(SceneDev S, QueueDev q,
             P.word[k][r] = philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), level,
                                          CFT_PURPOSE_SCAN0 + (k == 0 ? role0 : role1), k0, k1).x;
         }
-        pre[0][r] = precise_hit(S, ox, oy, oz, dx, dy, dz, P.word[0][r]);
-        if (NS == 2) pre[NS - 1][r] = S.prec_motion ? precise_hit(S, ox, oy, oz, dx, dy, dz, P.word[NS - 1][r]) : pre[0][r];
+        pre = precise_hit(S, ox, oy, oz, dx, dy, dz, P.word[0][r]);
       }
-      ray_setup<R, NS>(S, P, r, ox, oy, oz, dx, dy, dz, pre[0][r]);
-      if (!valid[r]) { P.thr4[r] = __builtin_inff(); P.negE[r] = __builtin_inff(); }   // a dummy slot never is a candidate
+      ray_setup<R, NS>(S, P, r, ox, oy, oz, dx, dy, dz, pre);
+      if (!(i < n)) { PK(P, thr4, r) = __builtin_inff(); P.negE16[r] = __builtin_inff(); }   // a dummy slot never is a candidate
       if (NS == 2 && S.prec_motion) P.U[r] = __builtin_inff();   // a moving precise sphere: no shared upper bound
     }
+    if (R & 1) pack_dummy_slot<R, NS>(P, R);
     scan_lists<R, NS>(S, P);
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        if (!valid[r]) continue;
         const uint32_t i = base + r * stride;
-        Closest c = ray_epilogue(S, P.ox[r], P.oy[r], P.oz[r], P.dx[r], P.dy[r], P.dz[r], P.word[k][r], P.c[k][r],
-                                 pre[k][r], stats);
+        if (!(i < n)) continue;
+        // the origin and the precise-sphere hit are not carried across the scan (registers): fetch / redo them
+        const float4 a = q.a[i];
+        const float dx = PK(P, dx, r), dy = PK(P, dy, r), dz = PK(P, dz, r);
+        const Closest pre = precise_hit(S, a.x, a.y, a.z, dx, dy, dz, P.word[k][r]);
+        Closest c = ray_epilogue(S, a.x, a.y, a.z, dx, dy, dz, P.word[k][r], P.c[k][r], pre, stats);
         float4 h0 = make_float4(__builtin_inff(), __int_as_float(-1), 0.f, 0.f);
         float4 h1 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c.g >= 0) {
-          d3 o = d3{(double)P.ox[r], (double)P.oy[r], (double)P.oz[r]};
-          d3 d = d3{(double)P.dx[r], (double)P.dy[r], (double)P.dz[r]};
+          d3 o = d3{(double)a.x, (double)a.y, (double)a.z};
+          d3 d = d3{(double)dx, (double)dy, (double)dz};
           d3 p = o + d * c.t;                        // point = pos + dir * t
           f3 nn = hit_normal(S, c.g, p, P.word[k][r]);
           h0 = make_float4((float)c.t, __int_as_float(c.g), (float)p.x, (float)p.y);

@@ -26,7 +26,7 @@ struct LightDev {  // device light list row
 struct SceneDev {
   // ---- f32 cull lists (hot loops) ----
   const float4* sphF;     // static, non-precise spheres: (-2c'x, -2c'y, -2c'z, 4(|c'|^2 - r^2)), c' = c - bc
-  const float* sphR2;     // their r^2 (read by the candidate path only)
+  const float* sphR2;     // 16 * their r^2 (f32-rounded r^2 scaled exactly), padded like sphF (fetched 4 at a time beside each sphF batch)
   const int* sphF_gid;    // -> global prim id
   int n_sphF;
   const float4* msphF;    // moving spheres, 2 float4 each: (cx, cy, cz, r^2) at time 0, (mvx, mvy, mvz, object id bits)
