@@ -56,7 +56,7 @@ def hbm_traffic_per_launch(rays_per_step, launches_per_step):
     PMC counters cannot be read inside the timed run."""
     path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
     try:
-        k = json.load(open(path))["kernels"]["k_intersect<2>"]
+        k = json.load(open(path))["kernels"]["k_intersect"]
     except (OSError, KeyError, ValueError):
         return None
     return k["bytes_per_ray"] * rays_per_step / max(launches_per_step, 1)

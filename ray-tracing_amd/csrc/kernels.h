@@ -19,6 +19,9 @@
 
 #define CFT_BLOCK 256
 #define CFT_SHADE_CHUNK 1024
+#ifndef CFT_SHADE_UNROLL
+#define CFT_SHADE_UNROLL 4   // ray sub-batches of a chunk in flight together (loads overlap)
+#endif
 #ifndef CFT_RAYS_PER_LANE
 #define CFT_RAYS_PER_LANE 4
 #endif
@@ -58,10 +61,12 @@ __device__ __forceinline__ bool exact_sphere(d3 o, d3 d, d3 c, double r, double*
   double delta = b * b - 4. * a * cc;
   if (delta < 0.) return false;
   double sq = sqrt(delta);
-  double t1 = (-b - sq) / (2. * a);
-  double t2 = (-b + sq) / (2. * a);
-  if (t2 < 0.) return false;
-  *t_out = t1 < 0. ? t2 : t1;
+  // The reference divides both roots by 2a and tests the quotients' signs; 2a > 0, so the signs are the
+  // numerators' (a quotient could only differ by underflowing to -0, which needs |numerator| < 2^-1021) and only
+  // the returned root is divided.
+  double n1 = -b - sq, n2 = -b + sq;
+  if (n2 < 0.) return false;
+  *t_out = (n1 < 0. ? n2 : n1) / (2. * a);
   return true;
 }
 // Triangle::hit_info, object.rs:100-120.
@@ -201,7 +206,13 @@ __device__ __forceinline__ float sphere_lower_bound(const SceneDev& S, float q, 
   const float aq = fabsf(q);
   const float e = fmaf(aq, S.K1, S.K2);                 // |disc - true disc| <= e
   const float eq = fmaf(aq, S.K3, S.K4);                // |q - true q| <= eq
-  const bool inside = fmaf(-q, q, d) > e;               // r^2 - |oc|^2 = disc - q^2 certainly > 0
+  const float io = fmaf(-q, q, d);                      // r^2 - |oc|^2 = disc - q^2
+  // |io - true| <= e + |q^2 - q*^2| + rounding of the fma
+  const float eio = e + fmaf(2.0f * aq + eq, eq, CFT_U4EPS * fmaf(aq, aq, fabsf(d)));
+  // The commonest candidate of a bounce ray is the sphere it just left: origin certainly outside (io < -eio)
+  // and moving away (q > eq), so both roots are negative.  Decided before the sqrt.
+  if (q > eq && io < -eio) return -1.0f;
+  const bool inside = io > eio;                         // r^2 - |oc|^2 certainly > 0
   const float arg = inside ? d - e : d + e;             // inside: disc > q^2 + e, so d - e > 0
   const float s = __builtin_amdgcn_sqrtf(fmaxf(arg, 0.0f));
   const float s_hi = fmaf(s, CFT_U4EPS, s), s_lo = fmaf(-s, CFT_U4EPS, s);
@@ -304,8 +315,30 @@ __device__ __forceinline__ v2f pair_cull(v2f cxy, v2f czk, v2f dx, v2f dy, v2f d
   return v;
 }
 
-// One static sphere against R rays: cull (above), then the lanes that pass recompute the cancellation-free
-// form (q, disc = r^2 - |oc - q d|^2) for the tight bound.
+// A sphere the cull could not rule out for ray slot r: recompute the cancellation-free form
+// (q, disc = r^2 - |oc - q d|^2), turn it into a lower bound and insert it.  Everything is scaled by 4 (16 for
+// squares), which is exact: 4 oc = 4 o' + 2 C is one rounding of the same real number as 4 (o' - c'), so
+// q4 = 4 q and d16 = 16 disc bit for bit.
+template <int R, int NS>
+__device__ __forceinline__ void sphere_candidate(const SceneDev& S, RayPack<R, NS>& P, int r, float Cx, float Cy,
+                                                 float Cz, float r2x16, int idx) {
+  const float dx = PK(P, dx, r), dy = PK(P, dy, r), dz = PK(P, dz, r);
+  float ocx = fmaf(2.0f, Cx, PK(P, o4x, r)), ocy = fmaf(2.0f, Cy, PK(P, o4y, r)), ocz = fmaf(2.0f, Cz, PK(P, o4z, r));
+  float q4 = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
+  float lx = fmaf(-q4, dx, ocx), ly = fmaf(-q4, dy, ocy), lz = fmaf(-q4, dz, ocz);
+  float d16 = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, r2x16)));
+  if (d16 >= P.negE16[r]) {
+    float tlo = sphere_lower_bound(S, 0.25f * q4, 0.0625f * d16, P.U[r]);
+    if (tlo >= 0.0f) {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) cand_insert(P.c[k][r], tlo, idx);
+    }
+  }
+}
+
+// One static sphere against R rays: cull (pair_cull), then the lanes that pass handle the candidate.
+// (Queueing the passing lanes' sphere indices in LDS and draining them after the scan, every lane on its own
+// sphere, was tried: 5 % fewer VALU instructions, no gain in time, +8 VGPRs - DESIGN.md §6.)
 template <int R, int NS>
 __device__ __forceinline__ void scan_sphere(const SceneDev& S, RayPack<R, NS>& P, v2f cxy, v2f czk, float r2x16,
                                             int idx) {
@@ -321,25 +354,9 @@ __device__ __forceinline__ void scan_sphere(const SceneDev& S, RayPack<R, NS>& P
   for (int h = 1; h < NP; ++h) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(V[h].x), "v"(V[h].y));
   const float k4 = czk.y;
   if (__builtin_amdgcn_ballot_w64(m >= k4) != 0ull) {
-    const float Cx = cxy.x, Cy = cxy.y, Cz = czk.x;
 #pragma unroll
     for (int r = 0; r < R; ++r)
-      if (V[r >> 1][r & 1] >= k4) {
-        // everything scaled by 4 (16 for squares), which is exact: 4 oc = 4 o' + 2 C is one rounding of the same
-        // real number as 4 (o' - c'), so q4 = 4 q and d16 = 16 disc bit for bit
-        const float dx = PK(P, dx, r), dy = PK(P, dy, r), dz = PK(P, dz, r);
-        float ocx = fmaf(2.0f, Cx, PK(P, o4x, r)), ocy = fmaf(2.0f, Cy, PK(P, o4y, r)), ocz = fmaf(2.0f, Cz, PK(P, o4z, r));
-        float q4 = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
-        float lx = fmaf(-q4, dx, ocx), ly = fmaf(-q4, dy, ocy), lz = fmaf(-q4, dz, ocz);
-        float d16 = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, r2x16)));
-        if (d16 >= P.negE16[r]) {
-          float tlo = sphere_lower_bound(S, 0.25f * q4, 0.0625f * d16, P.U[r]);
-          if (tlo >= 0.0f) {
-#pragma unroll
-            for (int k = 0; k < NS; ++k) cand_insert(P.c[k][r], tlo, idx);
-          }
-        }
-      }
+      if (V[r >> 1][r & 1] >= k4) sphere_candidate<R, NS>(S, P, r, cxy.x, cxy.y, czk.x, r2x16, idx);
   }
 }
 
@@ -474,7 +491,7 @@ __device__ __forceinline__ void ray_setup(const SceneDev& S, RayPack<R, NS>& P, 
   PK(P, od2, r) = 2.0f * fmaf(tz, dz, fmaf(ty, dy, tx * dx));
   const float oo = fmaf(tz, tz, fmaf(ty, ty, tx * tx));
   // |o'| + |c'| <= dist: bound of every magnitude in the scan (S.brad = largest |c'| incl. motion)
-  const float dist = sqrtf(oo) * 1.000001f + S.brad;
+  const float dist = __builtin_amdgcn_sqrtf(oo) * 1.000001f + S.brad;   // 1-ulp sqrt, covered by the factor
   P.negE16[r] = -16.0f * fmaf(dist, S.K1, S.K2);
   // cheap form: |4 disc' - 4 oo - 4 disc*| <= 4 Kc (dist^2 + rmax^2)  =>  pass iff  4 disc' >= 4 (oo - E)
   const float thr = fmaf(-S.Kc, fmaf(dist, dist, S.rmax2), oo);
@@ -597,9 +614,8 @@ __device__ __forceinline__ f3 hit_normal(const SceneDev& S, int g, d3 p, uint32_
   }
   f3 nf = mk3((float)n.x, (float)n.y, (float)n.z);
   float s = fmaxf(fmaxf(fabsf(nf.x), fabsf(nf.y)), fabsf(nf.z));   // keep |n|^2 inside the f32 range
-  float is = 1.0f / s;
-  nf = nf * is;
-  return nf * (1.0f / sqrtf(dot3(nf, nf)));
+  nf = nf * __builtin_amdgcn_rcpf(s);                              // 1-ulp rcp / rsq: k_shade renormalises anyway
+  return nf * __builtin_amdgcn_rsqf(dot3(nf, nf));
 }
 
 // one lane = R live rays of trace level `level` (ray i, i + stride, ...); primitive lists are
@@ -610,6 +626,7 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_intersect(SceneDev S, QueueDev q,
                                                          uint32_t level, uint64_t pid_base, uint32_t k0,
                                                          uint32_t k1, uint32_t role0, uint32_t role1, HitDev out0,
                                                          HitDev out1, uint32_t* stats) {
+  __shared__ float park[6 * R][CFT_BLOCK];
   const uint32_t n = counts[level];
   const uint32_t stride = gridDim.x * CFT_BLOCK;
   for (uint32_t base = blockIdx.x * CFT_BLOCK + threadIdx.x; base < n; base += stride * R) {
@@ -638,6 +655,12 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_intersect(SceneDev S, QueueDev q,
         }
         pre = precise_hit(S, ox, oy, oz, dx, dy, dz, P.word[0][r]);
       }
+      // the origin as given and the precise-sphere hit are needed again only after the scan: parked in LDS
+      // (this lane's own column, no barrier) instead of in registers
+      park[6 * r + 0][threadIdx.x] = ox; park[6 * r + 1][threadIdx.x] = oy; park[6 * r + 2][threadIdx.x] = oz;
+      park[6 * r + 3][threadIdx.x] = __int_as_float(__double2loint(pre.t));
+      park[6 * r + 4][threadIdx.x] = __int_as_float(__double2hiint(pre.t));
+      park[6 * r + 5][threadIdx.x] = __int_as_float(pre.g);
       ray_setup<R, NS>(S, P, r, ox, oy, oz, dx, dy, dz, pre);
       if (!(i < n)) { PK(P, thr4, r) = __builtin_inff(); P.negE16[r] = __builtin_inff(); }   // a dummy slot never is a candidate
       if (NS == 2 && S.prec_motion) P.U[r] = __builtin_inff();   // a moving precise sphere: no shared upper bound
@@ -645,15 +668,21 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_intersect(SceneDev S, QueueDev q,
     if (R & 1) pack_dummy_slot<R, NS>(P, R);
     scan_lists<R, NS>(S, P);
 #pragma unroll
-    for (int k = 0; k < NS; ++k) {
+    for (int r = 0; r < R; ++r) {
+      const uint32_t i = base + r * stride;
+      if (!(i < n)) continue;
+      const float3 a = make_float3(park[6 * r + 0][threadIdx.x], park[6 * r + 1][threadIdx.x], park[6 * r + 2][threadIdx.x]);
+      const float4 st = make_float4(park[6 * r + 3][threadIdx.x], park[6 * r + 4][threadIdx.x], park[6 * r + 5][threadIdx.x], 0.f);
+      const float dx = PK(P, dx, r), dy = PK(P, dy, r), dz = PK(P, dz, r);
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const uint32_t i = base + r * stride;
-        if (!(i < n)) continue;
-        // the origin and the precise-sphere hit are not carried across the scan (registers): fetch / redo them
-        const float4 a = q.a[i];
-        const float dx = PK(P, dx, r), dy = PK(P, dy, r), dz = PK(P, dz, r);
-        const Closest pre = precise_hit(S, a.x, a.y, a.z, dx, dy, dz, P.word[k][r]);
+      for (int k = 0; k < NS; ++k) {
+        Closest pre;
+        if (k == 0 || !S.prec_motion) {
+          pre.t = __hiloint2double(__float_as_int(st.y), __float_as_int(st.x));
+          pre.g = __float_as_int(st.z);
+        } else {
+          pre = precise_hit(S, a.x, a.y, a.z, dx, dy, dz, P.word[k][r]);
+        }
         Closest c = ray_epilogue(S, a.x, a.y, a.z, dx, dy, dz, P.word[k][r], P.c[k][r], pre, stats);
         float4 h0 = make_float4(__builtin_inff(), __int_as_float(-1), 0.f, 0.f);
         float4 h1 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -782,6 +811,7 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_shade(SceneDev S, QueueDev qin, H
   for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
    if (threadIdx.x == 0) s_cnt = 0;
    __syncthreads();
+#pragma unroll CFT_SHADE_UNROLL
    for (uint32_t rr = 0; rr < CFT_SHADE_CHUNK / CFT_BLOCK; ++rr) {
     uint32_t i = chunk * CFT_SHADE_CHUNK + rr * CFT_BLOCK + threadIdx.x;
     bool live = i < n;
