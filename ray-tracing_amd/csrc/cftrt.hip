@@ -505,6 +505,9 @@ static void launch_intersect(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, cons
                              uint64_t pid_base, uint32_t k0, uint32_t k1, bool two_scans, uint32_t role0, uint32_t role1,
                              HitDev out0, HitDev out1, uint32_t* xstats, uint32_t P) {
   int R = ctx->variant ? ctx->variant : CFT_RAYS_PER_LANE;
+  // few live rays (deep levels): fewer rays per lane spread them over more waves; below one wave per SIMD the
+  // launch time is one wave's latency through the list, which R = 2 halves against R = 4
+  if (!ctx->variant && P < (1u << 20)) R = 2;
   if (two_scans && R > 2) R = 2;
   const uint32_t g = grid_for(ctx, ((uint64_t)P + R - 1) / R, 8);
   hipStream_t st = ctx->stream;
@@ -600,13 +603,14 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
   hipLaunchKernelGGL(k_generate, dim3(grid_for(ctx, P, 16)), dim3(CFT_BLOCK), 0, st_, C, pid_base, P, k0, k1, jitter, q[0]);
   tm.end();
 
-  const uint32_t grid = grid_for(ctx, P, 8);
+  uint32_t ub = P;   // upper bound on the live rays of the current level (a ray spawns at most one ray)
   uint32_t levels_run = 0;
   for (uint32_t level = 0; level < max_depth; ++level) {
+    const uint32_t grid = grid_for(ctx, ub, 8);
     int in = level & 1, outq = in ^ 1;
     const uint32_t nl = (uint32_t)S.n_lights;
     tm.begin(CLS_ISECT);
-    launch_intersect(ctx, S, q[in], counts, level, pid_base, k0, k1, two_scans, two_scans ? 0u : nl, nl, hA, hB, xstats, P);
+    launch_intersect(ctx, S, q[in], counts, level, pid_base, k0, k1, two_scans, two_scans ? 0u : nl, nl, hA, hB, xstats, ub);
     tm.end();
     tm.begin(CLS_SHADE);
     hipLaunchKernelGGL(k_shade, dim3(grid), dim3(CFT_BLOCK), 0, st_, S, q[in], hA, hB, counts, level, max_depth, pid_base,
@@ -624,6 +628,7 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
       HIP_TRY(ctx, hipMemcpyAsync(ctx->host_counts, counts + level + 1, 4, hipMemcpyDeviceToHost, st_));
       HIP_TRY(ctx, hipStreamSynchronize(st_));
       if (ctx->host_counts[0] == 0) break;
+      ub = ctx->host_counts[0];
     }
   }
   if (accum_dev) {
