@@ -94,6 +94,8 @@ def main():
     dev = rt.Device(local_rank)
     if os.environ.get("CFTRT_VARIANT"):
         dev.set_variant(int(os.environ["CFTRT_VARIANT"]))
+    split = os.environ.get("CFTRT_PIPELINE", "fused") == "split"   # profiling aid: the two stages as separate kernels
+    dev.set_pipeline(split)
     scene.commit(dev)
     accum = torch.zeros(H * W * 3, dtype=torch.float32, device=f"cuda:{local_rank}")
     spp_begin, spp_end = rank * spp, (rank + 1) * spp

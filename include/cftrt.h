@@ -116,7 +116,12 @@ void cftrt_ctx_destroy(cftrt_ctx* ctx);
 const char* cftrt_last_error(const cftrt_ctx* ctx);
 /* Cap on the path workspace (bytes of HBM the render calls may hold; default 40 GiB). */
 int cftrt_ctx_set_workspace_limit(cftrt_ctx* ctx, uint64_t bytes);
-/* Intersect-kernel variant: rays per lane of k_intersect (1..4); 0 = the tuned default. */
+/* Pipeline per trace level: 0 (default) = one fused launch (k_trace_level: intersect, shade and queue append),
+ * 1 = split (k_intersect -> hit records in HBM -> k_shade), the form the kernels are profiled in separately.
+ * Both produce the same image bit for bit.  In fused mode cftrt_stats.ms_intersect / flops_intersect /
+ * launches_intersect describe the fused kernel and ms_shade is 0. */
+int cftrt_ctx_set_pipeline(cftrt_ctx* ctx, int split);
+/* Intersect-kernel variant: rays per lane of k_intersect / k_trace_level (1..4); 0 = the tuned default. */
 int cftrt_ctx_set_variant(cftrt_ctx* ctx, int variant);
 
 /* ---- scene (replaces World::empty/add_obj/add_light, src/object.rs:311-324) ------------- */

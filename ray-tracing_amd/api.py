@@ -349,6 +349,10 @@ class Device:
     def set_workspace_limit(self, nbytes):
         self.check(self.lib.cftrt_ctx_set_workspace_limit(self.h, int(nbytes)))
 
+    def set_pipeline(self, split):
+        """False/0 = fused k_trace_level per level (default), True/1 = k_intersect + k_shade with hit records."""
+        self.check(self.lib.cftrt_ctx_set_pipeline(self.h, int(bool(split))))
+
     def set_variant(self, v):
         self.check(self.lib.cftrt_ctx_set_variant(self.h, int(v)))
 

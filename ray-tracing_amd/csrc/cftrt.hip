@@ -23,6 +23,7 @@ struct cftrt_ctx {
   std::string err;
   uint64_t ws_limit = 40ull << 30;
   int variant = 0;
+  int split = 0;          // 0: fused k_trace_level per level (default); 1: k_intersect -> hit records -> k_shade
   int n_cu = 256;
   // grow-only workspace
   DevBuf qa[2], qb[2], qc[2], h0[2], h1[2], rad, pqa, pqb, pqc, pqd, counts, accum_tmp, misc;
@@ -157,6 +158,13 @@ int cftrt_ctx_set_workspace_limit(cftrt_ctx* ctx, uint64_t bytes) {
   if (!ctx) return CFTRT_ERR_INVALID;
   if (bytes < (64ull << 20)) return fail(ctx, CFTRT_ERR_LIMIT, "workspace limit below 64 MiB");
   ctx->ws_limit = bytes;
+  return CFTRT_OK;
+}
+
+int cftrt_ctx_set_pipeline(cftrt_ctx* ctx, int split) {
+  if (!ctx) return CFTRT_ERR_INVALID;
+  if (split != 0 && split != 1) return fail(ctx, CFTRT_ERR_INVALID, "pipeline must be 0 (fused) or 1 (split)");
+  ctx->split = split;
   return CFTRT_OK;
 }
 
@@ -526,6 +534,31 @@ static void launch_intersect(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, cons
 #undef CFT_LAUNCH
 }
 
+// k_trace_level<R, NS>: the fused pipeline's one launch per level (same R / NS choice as launch_intersect).
+static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, uint32_t* counts, uint32_t level,
+                               uint32_t max_depth, uint64_t pid_base, uint32_t k0, uint32_t k1, bool two_scans,
+                               uint32_t role0, uint32_t role1, QueueDev qout, float4* rad, PhongQueueDev pq,
+                               uint32_t* phong_counts, uint32_t* xstats, uint32_t P) {
+  int R = ctx->variant ? ctx->variant : CFT_RAYS_PER_LANE;
+  if (!ctx->variant && P < (1u << 20)) R = 2;
+  if (two_scans && R > 2) R = 2;
+  const uint32_t g = grid_for(ctx, ((uint64_t)P + R - 1) / R, 8);
+  hipStream_t st = ctx->stream;
+#define CFT_LAUNCH(RR, NN) hipLaunchKernelGGL((k_trace_level<RR, NN>), dim3(g), dim3(CFT_BLOCK), 0, st, S, q, counts, level, \
+                                              max_depth, pid_base, k0, k1, role0, role1, qout, rad, pq, phong_counts, xstats)
+  if (two_scans) {
+    if (R == 1) CFT_LAUNCH(1, 2); else CFT_LAUNCH(2, 2);
+  } else {
+    switch (R) {
+      case 1: CFT_LAUNCH(1, 1); break;
+      case 3: CFT_LAUNCH(3, 1); break;
+      case 4: CFT_LAUNCH(4, 1); break;
+      default: CFT_LAUNCH(2, 1); break;
+    }
+  }
+#undef CFT_LAUNCH
+}
+
 struct EvTimer {   // pairs of events around launches on the ctx stream, summed per class after a sync
   cftrt_ctx* ctx;
   size_t used = 0;
@@ -572,7 +605,7 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
     if ((rc = ensure(ctx, ctx->qb[k], (size_t)P * 16))) return rc;
     if ((rc = ensure(ctx, ctx->qc[k], (size_t)P * 8))) return rc;
   }
-  for (int k = 0; k < (two_scans ? 2 : 1); ++k) {
+  for (int k = 0; ctx->split && k < (two_scans ? 2 : 1); ++k) {   // hit records: split pipeline only
     if ((rc = ensure(ctx, ctx->h0[k], (size_t)P * 16))) return rc;
     if ((rc = ensure(ctx, ctx->h1[k], (size_t)P * 16))) return rc;
   }
@@ -609,13 +642,20 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
     const uint32_t grid = grid_for(ctx, ub, 8);
     int in = level & 1, outq = in ^ 1;
     const uint32_t nl = (uint32_t)S.n_lights;
-    tm.begin(CLS_ISECT);
-    launch_intersect(ctx, S, q[in], counts, level, pid_base, k0, k1, two_scans, two_scans ? 0u : nl, nl, hA, hB, xstats, ub);
-    tm.end();
-    tm.begin(CLS_SHADE);
-    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(CFT_BLOCK), 0, st_, S, q[in], hA, hB, counts, level, max_depth, pid_base,
-                       k0, k1, q[outq], rad, pq, phong_counts);
-    tm.end();
+    if (!ctx->split) {
+      tm.begin(CLS_ISECT);   // the fused kernel is booked as the intersect class (ms_shade stays 0)
+      launch_trace_level(ctx, S, q[in], counts, level, max_depth, pid_base, k0, k1, two_scans, two_scans ? 0u : nl, nl,
+                         q[outq], rad, pq, phong_counts, xstats, ub);
+      tm.end();
+    } else {
+      tm.begin(CLS_ISECT);
+      launch_intersect(ctx, S, q[in], counts, level, pid_base, k0, k1, two_scans, two_scans ? 0u : nl, nl, hA, hB, xstats, ub);
+      tm.end();
+      tm.begin(CLS_SHADE);
+      hipLaunchKernelGGL(k_shade, dim3(grid), dim3(CFT_BLOCK), 0, st_, S, q[in], hA, hB, counts, level, max_depth,
+                         pid_base, k0, k1, q[outq], rad, pq, phong_counts);
+      tm.end();
+    }
     if (phong) {
       tm.begin(CLS_SHADOW);
       hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(CFT_BLOCK), 0, st_, S, pq, phong_counts, level, pid_base, k0, k1, rad,
@@ -670,7 +710,7 @@ static int render_impl(cftrt_scene* s, const cftrt_camera* cam, uint32_t width, 
   const uint64_t npix = (uint64_t)width * height;
   if (npix > (1ull << 31)) return fail(ctx, CFTRT_ERR_LIMIT, "image beyond 2^31 pixels");
   const bool two_scans = s->dev.any_motion && s->dev.n_lights > 0;
-  const uint64_t bytes_per_path = 80 + 16 + (two_scans ? 64 : 32) + (s->dev.n_phong_mats ? 56 : 0);
+  const uint64_t bytes_per_path = 80 + 16 + (ctx->split ? (two_scans ? 64 : 32) : 0) + (s->dev.n_phong_mats ? 56 : 0);
   uint64_t spp_pass = ctx->ws_limit / (bytes_per_path * npix);
   spp_pass = std::min<uint64_t>(spp_pass, 0xFFFFFF00ull / npix);
   if (spp_pass == 0) return fail(ctx, CFTRT_ERR_LIMIT, "one sample per pixel does not fit the workspace limit");

@@ -618,82 +618,139 @@ __device__ __forceinline__ f3 hit_normal(const SceneDev& S, int g, d3 p, uint32_
   return nf * __builtin_amdgcn_rsqf(dot3(nf, nf));
 }
 
+// ---- pieces shared by k_intersect and the fused k_trace_level
+// LDS "park": what a ray needs only AFTER the scan lives in the lane's own LDS column (no barrier) instead of
+// in registers, and the per-ray work after the scan runs as a rolled loop over the R slots that indexes the
+// park dynamically - one copy of the f64 / shading code and its registers, not R.  Words of slot r:
+//   [0..2] precise-sphere hit (t lo, t hi, prim)   [3 + 5k ..] candidate set of scan k   [3 + 5 NS + k] motion word k
+// The fused kernel later reuses a slot's words for the surviving ray (9 words).
+template <int NS> struct ParkLayout {
+  static constexpr int CAND = 3, WORD = 3 + 5 * NS, WORDS = (4 + 6 * NS) > 9 ? (3 + 6 * NS) : 9;
+};
+#define PARK(r, j) park[(r) * ParkLayout<NS>::WORDS + (j)][threadIdx.x]
+
+// Before the scan: load the lane's R rays of this level (ray i, i + stride, ...), draw the motion words, test the
+// precise spheres, fill the pack.
+template <int R, int NS>
+__device__ __forceinline__ void isect_setup(const SceneDev& S, const QueueDev& q, uint32_t n, uint32_t base,
+                                            uint32_t stride, uint32_t level, uint64_t pid_base, uint32_t k0,
+                                            uint32_t k1, uint32_t role0, uint32_t role1, RayPack<R, NS>& P,
+                                            float (*park)[CFT_BLOCK]) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint32_t i = base + r * stride;
+    float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 1.f;
+    Closest pre;
+    pre.t = __builtin_inf(); pre.g = -1;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      P.word[k][r] = 0;
+      cand_init(P.c[k][r]);
+    }
+    if (i < n) {
+      float4 a = q.a[i];
+      float4 b = q.b[i];
+      ox = a.x; oy = a.y; oz = a.z; dx = a.w; dy = b.x; dz = b.y;
+      if (S.any_motion) {
+        uint64_t pid = pid_base + __float_as_uint(q.c[i].y);
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+          P.word[k][r] = philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), level,
+                                       CFT_PURPOSE_SCAN0 + (k == 0 ? role0 : role1), k0, k1).x;
+      }
+      pre = precise_hit(S, ox, oy, oz, dx, dy, dz, P.word[0][r]);
+    }
+    PARK(r, 0) = __int_as_float(__double2loint(pre.t));
+    PARK(r, 1) = __int_as_float(__double2hiint(pre.t));
+    PARK(r, 2) = __int_as_float(pre.g);
+    ray_setup<R, NS>(S, P, r, ox, oy, oz, dx, dy, dz, pre);
+    if (!(i < n)) { PK(P, thr4, r) = __builtin_inff(); P.negE16[r] = __builtin_inff(); }   // a dummy slot never is a candidate
+    if (NS == 2 && S.prec_motion) P.U[r] = __builtin_inff();   // a moving precise sphere: no shared upper bound
+  }
+  if (R & 1) pack_dummy_slot<R, NS>(P, R);
+}
+
+// Right after the scan: the candidate sets and motion words join the park; the pack is dead from here on.
+template <int R, int NS>
+__device__ __forceinline__ void isect_park(const RayPack<R, NS>& P, float (*park)[CFT_BLOCK]) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      const Cand& c = P.c[k][r];
+      PARK(r, ParkLayout<NS>::CAND + 5 * k + 0) = c.lo1;
+      PARK(r, ParkLayout<NS>::CAND + 5 * k + 1) = c.lo2;
+      PARK(r, ParkLayout<NS>::CAND + 5 * k + 2) = c.lo3;
+      PARK(r, ParkLayout<NS>::CAND + 5 * k + 3) = __int_as_float(c.i1);
+      PARK(r, ParkLayout<NS>::CAND + 5 * k + 4) = __int_as_float(c.i2);
+      PARK(r, ParkLayout<NS>::WORD + k) = __uint_as_float(P.word[k][r]);
+    }
+  }
+}
+
+// The hit record of slot r (any r: the park is indexed dynamically), scan k, for the ray (o, d) re-read from the
+// queue: (t, prim, px, py), (pz, nx, ny, nz); prim = -1 on a miss.
+template <int NS>
+__device__ __forceinline__ void isect_hit(const SceneDev& S, int r, int k, float ox, float oy, float oz, float dx,
+                                          float dy, float dz, float (*park)[CFT_BLOCK], uint32_t* stats, float4* h0,
+                                          float4* h1) {
+  const uint32_t word = __float_as_uint(PARK(r, ParkLayout<NS>::WORD + k));
+  Closest pre;
+  if (k == 0 || !S.prec_motion) {
+    pre.t = __hiloint2double(__float_as_int(PARK(r, 1)), __float_as_int(PARK(r, 0)));
+    pre.g = __float_as_int(PARK(r, 2));
+  } else {
+    pre = precise_hit(S, ox, oy, oz, dx, dy, dz, word);
+  }
+  Cand cd;
+  cd.lo1 = PARK(r, ParkLayout<NS>::CAND + 5 * k + 0);
+  cd.lo2 = PARK(r, ParkLayout<NS>::CAND + 5 * k + 1);
+  cd.lo3 = PARK(r, ParkLayout<NS>::CAND + 5 * k + 2);
+  cd.i1 = __float_as_int(PARK(r, ParkLayout<NS>::CAND + 5 * k + 3));
+  cd.i2 = __float_as_int(PARK(r, ParkLayout<NS>::CAND + 5 * k + 4));
+  Closest c = ray_epilogue(S, ox, oy, oz, dx, dy, dz, word, cd, pre, stats);
+  *h0 = make_float4(__builtin_inff(), __int_as_float(-1), 0.f, 0.f);
+  *h1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c.g >= 0) {
+    d3 o = d3{(double)ox, (double)oy, (double)oz};
+    d3 d = d3{(double)dx, (double)dy, (double)dz};
+    d3 p = o + d * c.t;                        // point = pos + dir * t
+    f3 nn = hit_normal(S, c.g, p, word);
+    *h0 = make_float4((float)c.t, __int_as_float(c.g), (float)p.x, (float)p.y);
+    *h1 = make_float4((float)p.z, nn.x, nn.y, nn.z);
+  }
+}
+
 // one lane = R live rays of trace level `level` (ray i, i + stride, ...); primitive lists are
 // wave-uniform SGPR operands.  NS = 1: one scan with motion key `role0`.  NS = 2 (scenes with moving
 // objects AND lights): the lights' `looked` scan (role0 -> out0) and trace's own (role1 -> out1) in one pass.
+// This is the intersect stage of the SPLIT pipeline (k_intersect -> hit records -> k_shade); the default
+// pipeline runs the same code fused with the shading (k_trace_level below).
 template <int R, int NS>
 __global__ __launch_bounds__(CFT_BLOCK) void k_intersect(SceneDev S, QueueDev q, const uint32_t* counts,
                                                          uint32_t level, uint64_t pid_base, uint32_t k0,
                                                          uint32_t k1, uint32_t role0, uint32_t role1, HitDev out0,
                                                          HitDev out1, uint32_t* stats) {
-  __shared__ float park[6 * R][CFT_BLOCK];
+  __shared__ float park[ParkLayout<NS>::WORDS * R][CFT_BLOCK];
   const uint32_t n = counts[level];
   const uint32_t stride = gridDim.x * CFT_BLOCK;
   for (uint32_t base = blockIdx.x * CFT_BLOCK + threadIdx.x; base < n; base += stride * R) {
-    RayPack<R, NS> P;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const uint32_t i = base + r * stride;
-      float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 1.f;
-      Closest pre;
-      pre.t = __builtin_inf(); pre.g = -1;
-#pragma unroll
-      for (int k = 0; k < NS; ++k) {
-        P.word[k][r] = 0;
-        cand_init(P.c[k][r]);
-      }
-      if (i < n) {
-        float4 a = q.a[i];
-        float4 b = q.b[i];
-        ox = a.x; oy = a.y; oz = a.z; dx = a.w; dy = b.x; dz = b.y;
-        if (S.any_motion) {
-          uint64_t pid = pid_base + __float_as_uint(q.c[i].y);
-#pragma unroll
-          for (int k = 0; k < NS; ++k)
-            P.word[k][r] = philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), level,
-                                         CFT_PURPOSE_SCAN0 + (k == 0 ? role0 : role1), k0, k1).x;
-        }
-        pre = precise_hit(S, ox, oy, oz, dx, dy, dz, P.word[0][r]);
-      }
-      // the origin as given and the precise-sphere hit are needed again only after the scan: parked in LDS
-      // (this lane's own column, no barrier) instead of in registers
-      park[6 * r + 0][threadIdx.x] = ox; park[6 * r + 1][threadIdx.x] = oy; park[6 * r + 2][threadIdx.x] = oz;
-      park[6 * r + 3][threadIdx.x] = __int_as_float(__double2loint(pre.t));
-      park[6 * r + 4][threadIdx.x] = __int_as_float(__double2hiint(pre.t));
-      park[6 * r + 5][threadIdx.x] = __int_as_float(pre.g);
-      ray_setup<R, NS>(S, P, r, ox, oy, oz, dx, dy, dz, pre);
-      if (!(i < n)) { PK(P, thr4, r) = __builtin_inff(); P.negE16[r] = __builtin_inff(); }   // a dummy slot never is a candidate
-      if (NS == 2 && S.prec_motion) P.U[r] = __builtin_inff();   // a moving precise sphere: no shared upper bound
+    {
+      RayPack<R, NS> P;
+      isect_setup<R, NS>(S, q, n, base, stride, level, pid_base, k0, k1, role0, role1, P, park);
+      scan_lists<R, NS>(S, P);
+      isect_park<R, NS>(P, park);
     }
-    if (R & 1) pack_dummy_slot<R, NS>(P, R);
-    scan_lists<R, NS>(S, P);
-#pragma unroll
+#pragma unroll 1
     for (int r = 0; r < R; ++r) {
       const uint32_t i = base + r * stride;
-      if (!(i < n)) continue;
-      const float3 a = make_float3(park[6 * r + 0][threadIdx.x], park[6 * r + 1][threadIdx.x], park[6 * r + 2][threadIdx.x]);
-      const float4 st = make_float4(park[6 * r + 3][threadIdx.x], park[6 * r + 4][threadIdx.x], park[6 * r + 5][threadIdx.x], 0.f);
-      const float dx = PK(P, dx, r), dy = PK(P, dy, r), dz = PK(P, dz, r);
+      if (!(i < n)) break;
+      const float4 a = q.a[i];
+      const float4 b = q.b[i];
 #pragma unroll
       for (int k = 0; k < NS; ++k) {
-        Closest pre;
-        if (k == 0 || !S.prec_motion) {
-          pre.t = __hiloint2double(__float_as_int(st.y), __float_as_int(st.x));
-          pre.g = __float_as_int(st.z);
-        } else {
-          pre = precise_hit(S, a.x, a.y, a.z, dx, dy, dz, P.word[k][r]);
-        }
-        Closest c = ray_epilogue(S, a.x, a.y, a.z, dx, dy, dz, P.word[k][r], P.c[k][r], pre, stats);
-        float4 h0 = make_float4(__builtin_inff(), __int_as_float(-1), 0.f, 0.f);
-        float4 h1 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c.g >= 0) {
-          d3 o = d3{(double)a.x, (double)a.y, (double)a.z};
-          d3 d = d3{(double)dx, (double)dy, (double)dz};
-          d3 p = o + d * c.t;                        // point = pos + dir * t
-          f3 nn = hit_normal(S, c.g, p, P.word[k][r]);
-          h0 = make_float4((float)c.t, __int_as_float(c.g), (float)p.x, (float)p.y);
-          h1 = make_float4((float)p.z, nn.x, nn.y, nn.z);
-        }
+        float4 h0, h1;
+        isect_hit<NS>(S, r, k, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &h0, &h1);
         if (k == 0) { out0.h0[i] = h0; out0.h1[i] = h1; }
         else        { out1.h0[i] = h0; out1.h1[i] = h1; }
       }
@@ -793,8 +850,115 @@ struct PhongQueueDev {   // Phong hits handed to k_shadow: 64 B per entry
   uint2* d;    // path id, material id
 };
 
-// one lane = one (ray, hit) record of this level.  hitA = the lights' `looked` scan, hitB = trace's
-// own scan (the same buffers for a static scene).
+// World::trace for one (ray, hit) of this level (object.rs:326-355): lights' `looked`, then the material.
+// H supplies the hit records lazily: A0() = (t, prim, ..) of the lights' `looked` scan, B0()/B1() = both words
+// of trace's own scan (the same scan for a static scene).  Writes the path's radiance when it terminates,
+// queues Phong hits for k_shadow, and returns whether the path continues (then *npos, *ndir, *thr are the next
+// ray and the updated throughput).
+template <typename H>
+__device__ __forceinline__ bool shade_one(const SceneDev& S, const H& hit, f3 pos, f3 dir, f3* thr_io, uint32_t lpid,
+                                          uint32_t level, uint32_t max_depth, uint64_t pid_base, uint32_t k0,
+                                          uint32_t k1, float4* radiance, const PhongQueueDev& pq,
+                                          uint32_t* phong_counts, f3* npos_out, f3* ndir_out) {
+  f3 thr = *thr_io;
+  f3 npos = mk3(0, 0, 0), ndir = mk3(0, 0, 0);
+  bool alive = false;
+  const float4 A0 = hit.A0();
+  const int primA = __float_as_int(A0.y);
+  // ---- lights: LightSource::looked (object.rs:333-341)
+  bool see = false;
+  f3 col = mk3(0, 0, 0);
+  for (int l = 0; l < S.n_lights; ++l) {
+    const LightDev L = S.lights[l];
+    if (L.kind == 0) {                       // SkyLight::looked, light.rs:184-190
+      if (primA < 0) { see = true; col = col + sky_color_from(dir); }
+    } else if (L.kind == 1) {                // LightShape::looked, light.rs:233-242
+      double tl;
+      if (light_shape_hit(S, L, pos, dir, &tl)) {
+        if (primA < 0 || tl < (double)A0.x) { see = true; col = col + mk3(L.r, L.g, L.b); }
+      }
+    }
+  }
+  if (see) {
+    radiance[lpid] = make_float4(thr.x * col.x, thr.y * col.y, thr.z * col.z, 0.f);
+  } else {
+    const float4 B0 = hit.B0();
+    const int prim = __float_as_int(B0.y);
+    if (prim < 0) {
+      radiance[lpid] = make_float4(0.f, 0.f, 0.f, 0.f);   // object.rs:354
+    } else {
+      const float4 B1 = hit.B1();
+      HitInfoF h = hitinfo_new(mk3(B1.y, B1.z, B1.w), mk3(B0.z, B0.w, B1.x), dir);
+      const MatDev m = S.mats[S.prim_mat[prim]];
+      uint64_t pid = pid_base + lpid;
+      f3 k = mk3(1, 1, 1);
+      bool scattered = true;
+      // Lambertian, Metal and Dielectric draw from the same Philox block (purpose = scatter of this level);
+      // drawn once for the wave, not once per material branch
+      u4 rnd = u4{0u, 0u, 0u, 0u};
+      if (m.kind <= 2) rnd = philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), level, CFT_PURPOSE_SCATTER, k0, k1);
+      switch (m.kind) {
+        case 0:     // LambertianModel, compose.rs:110-119: lobe radius 1, k = albedo * colour
+        case 1: {   // Metal, compose.rs:42-52: lobe radius fuzz (p0), k = albedo (p1) * colour
+          const float radius = m.kind == 0 ? 1.0f : m.p0, alb = m.kind == 0 ? m.p0 : m.p1;
+          npos = hi_pos(h);
+          ndir = unit3(h.dout + gen_point_in_sphere(radius, u24f(rnd.x), u24f(rnd.y)));
+          k = mk3(alb * m.r, alb * m.g, alb * m.b);
+        } break;
+        case 2: {   // Dielectric, compose.rs:74-88
+          bool refl = u24f(rnd.x) < hi_reflect_prob(h, m.p0);
+          if (!refl) {
+            float ratio = h.outward ? m.p0 : 1.0f / m.p0;
+            refl = !hi_refract(h, ratio, &npos, &ndir);   // total reflection -> reflect
+          }
+          if (refl) { npos = hi_pos(h); ndir = h.dout; }
+        } break;
+        case 4: {   // Specular, basic.rs:120-124 (default scatter = reflect)
+          npos = hi_pos(h); ndir = h.dout;
+          k = mk3(m.p0, m.p0, m.p0);
+        } break;
+        case 5: {   // Transparent, basic.rs:168-184
+          float ratio = h.outward ? m.p1 : 1.0f / m.p1;
+          if (!hi_refract(h, ratio, &npos, &ndir)) { npos = hi_pos(h); ndir = h.dout; }
+          float sc = 1.0f - m.p0;
+          k = mk3(m.r * sc, m.g * sc, m.b * sc);
+        } break;
+        default: {  // PhongModel: terminal, handed to k_shadow
+          scattered = false;
+          uint32_t slot = atomicAdd(&phong_counts[level], 1u);
+          pq.a[slot] = make_float4(h.p.x, h.p.y, h.p.z, h.n.x);
+          pq.b[slot] = make_float4(h.n.y, h.n.z, h.dout.x, h.dout.y);
+          pq.c[slot] = make_float4(h.dout.z, thr.x, thr.y, thr.z);
+          pq.d[slot] = make_uint2(lpid, (uint32_t)S.prim_mat[prim]);
+        } break;
+      }
+      if (scattered) {
+        thr = thr * k;
+        if (level + 1 < max_depth) alive = true;
+        else radiance[lpid] = make_float4(0.f, 0.f, 0.f, 0.f);   // trace(.., 0) is black (object.rs:327-329)
+      }
+    }
+  }
+  *thr_io = thr; *npos_out = npos; *ndir_out = ndir;
+  return alive;
+}
+
+struct HitFromRecords {   // the split pipeline: hit records written by k_intersect, loaded on demand
+  HitDev A, B;
+  uint32_t i;
+  __device__ __forceinline__ float4 A0() const { return A.h0[i]; }
+  __device__ __forceinline__ float4 B0() const { return B.h0[i]; }
+  __device__ __forceinline__ float4 B1() const { return B.h1[i]; }
+};
+struct HitInRegisters {   // the fused pipeline
+  float4 a0, b0, b1;
+  __device__ __forceinline__ float4 A0() const { return a0; }
+  __device__ __forceinline__ float4 B0() const { return b0; }
+  __device__ __forceinline__ float4 B1() const { return b1; }
+};
+
+// SPLIT pipeline, shade stage: one lane = one (ray, hit) record of this level.  hitA = the lights' `looked`
+// scan, hitB = trace's own scan (the same buffers for a static scene).
 __global__ __launch_bounds__(CFT_BLOCK) void k_shade(SceneDev S, QueueDev qin, HitDev hitA, HitDev hitB,
                                                      uint32_t* counts, uint32_t level, uint32_t max_depth,
                                                      uint64_t pid_base, uint32_t k0, uint32_t k1, QueueDev qout,
@@ -814,95 +978,17 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_shade(SceneDev S, QueueDev qin, H
 #pragma unroll CFT_SHADE_UNROLL
    for (uint32_t rr = 0; rr < CFT_SHADE_CHUNK / CFT_BLOCK; ++rr) {
     uint32_t i = chunk * CFT_SHADE_CHUNK + rr * CFT_BLOCK + threadIdx.x;
-    bool live = i < n;
     bool alive = false;          // continues to the next level
     f3 npos = mk3(0, 0, 0), ndir = mk3(0, 0, 0), thr = mk3(0, 0, 0);
     uint32_t lpid = 0;
-    if (live) {
+    if (i < n) {
       float4 a = qin.a[i];
       float4 b = qin.b[i];
       float2 c = qin.c[i];
-      f3 pos = mk3(a.x, a.y, a.z), dir = mk3(a.w, b.x, b.y);
       thr = mk3(b.z, b.w, c.x);
       lpid = __float_as_uint(c.y);
-      float4 A0 = hitA.h0[i];
-      int primA = __float_as_int(A0.y);
-      // ---- lights: LightSource::looked (object.rs:333-341)
-      bool see = false;
-      f3 col = mk3(0, 0, 0);
-      for (int l = 0; l < S.n_lights; ++l) {
-        const LightDev L = S.lights[l];
-        if (L.kind == 0) {                       // SkyLight::looked, light.rs:184-190
-          if (primA < 0) { see = true; col = col + sky_color_from(dir); }
-        } else if (L.kind == 1) {                // LightShape::looked, light.rs:233-242
-          double tl;
-          if (light_shape_hit(S, L, pos, dir, &tl)) {
-            if (primA < 0 || tl < (double)A0.x) { see = true; col = col + mk3(L.r, L.g, L.b); }
-          }
-        }
-      }
-      if (see) {
-        radiance[lpid] = make_float4(thr.x * col.x, thr.y * col.y, thr.z * col.z, 0.f);
-      } else {
-        float4 B0 = hitB.h0[i];
-        int prim = __float_as_int(B0.y);
-        if (prim < 0) {
-          radiance[lpid] = make_float4(0.f, 0.f, 0.f, 0.f);   // object.rs:354
-        } else {
-          float4 B1 = hitB.h1[i];
-          HitInfoF h = hitinfo_new(mk3(B1.y, B1.z, B1.w), mk3(B0.z, B0.w, B1.x), dir);
-          const MatDev m = S.mats[S.prim_mat[prim]];
-          uint64_t pid = pid_base + lpid;
-          f3 k = mk3(1, 1, 1);
-          bool scattered = true;
-          switch (m.kind) {
-            case 0: {   // LambertianModel, compose.rs:110-119
-              u4 r = philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), level, CFT_PURPOSE_SCATTER, k0, k1);
-              npos = hi_pos(h);
-              ndir = unit3(h.dout + gen_point_in_sphere(1.0f, u24f(r.x), u24f(r.y)));
-              k = mk3(m.r * m.p0, m.g * m.p0, m.b * m.p0);
-            } break;
-            case 1: {   // Metal, compose.rs:42-52
-              u4 r = philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), level, CFT_PURPOSE_SCATTER, k0, k1);
-              npos = hi_pos(h);
-              ndir = unit3(h.dout + gen_point_in_sphere(m.p0, u24f(r.x), u24f(r.y)));
-              k = mk3(m.p1 * m.r, m.p1 * m.g, m.p1 * m.b);
-            } break;
-            case 2: {   // Dielectric, compose.rs:74-88
-              u4 r = philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), level, CFT_PURPOSE_SCATTER, k0, k1);
-              bool refl = u24f(r.x) < hi_reflect_prob(h, m.p0);
-              if (!refl) {
-                float ratio = h.outward ? m.p0 : 1.0f / m.p0;
-                refl = !hi_refract(h, ratio, &npos, &ndir);   // total reflection -> reflect
-              }
-              if (refl) { npos = hi_pos(h); ndir = h.dout; }
-            } break;
-            case 4: {   // Specular, basic.rs:120-124 (default scatter = reflect)
-              npos = hi_pos(h); ndir = h.dout;
-              k = mk3(m.p0, m.p0, m.p0);
-            } break;
-            case 5: {   // Transparent, basic.rs:168-184
-              float ratio = h.outward ? m.p1 : 1.0f / m.p1;
-              if (!hi_refract(h, ratio, &npos, &ndir)) { npos = hi_pos(h); ndir = h.dout; }
-              float s = 1.0f - m.p0;
-              k = mk3(m.r * s, m.g * s, m.b * s);
-            } break;
-            default: {  // PhongModel: terminal, handed to k_shadow
-              scattered = false;
-              uint32_t slot = atomicAdd(&phong_counts[level], 1u);
-              pq.a[slot] = make_float4(h.p.x, h.p.y, h.p.z, h.n.x);
-              pq.b[slot] = make_float4(h.n.y, h.n.z, h.dout.x, h.dout.y);
-              pq.c[slot] = make_float4(h.dout.z, thr.x, thr.y, thr.z);
-              pq.d[slot] = make_uint2(lpid, (uint32_t)S.prim_mat[prim]);
-            } break;
-          }
-          if (scattered) {
-            thr = thr * k;
-            if (level + 1 < max_depth) alive = true;
-            else radiance[lpid] = make_float4(0.f, 0.f, 0.f, 0.f);   // trace(.., 0) is black (object.rs:327-329)
-          }
-        }
-      }
+      alive = shade_one(S, HitFromRecords{hitA, hitB, i}, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), &thr, lpid, level,
+                        max_depth, pid_base, k0, k1, radiance, pq, phong_counts, &npos, &ndir);
     }
     // ---- stage survivors in LDS: one LDS atomic per wave (ballot + prefix count)
     unsigned long long mask = __ballot(alive);
@@ -914,10 +1000,10 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_shade(SceneDev S, QueueDev qin, H
       base = __shfl(base, 0);
       if (alive) {
         uint32_t off = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        uint32_t s = base + off;
-        s_a[s] = make_float4(npos.x, npos.y, npos.z, ndir.x);
-        s_b[s] = make_float4(ndir.y, ndir.z, thr.x, thr.y);
-        s_c[s] = make_float2(thr.z, __uint_as_float(lpid));
+        uint32_t sl = base + off;
+        s_a[sl] = make_float4(npos.x, npos.y, npos.z, ndir.x);
+        s_b[sl] = make_float4(ndir.y, ndir.z, thr.x, thr.y);
+        s_c[sl] = make_float2(thr.z, __uint_as_float(lpid));
       }
     }
    }
@@ -932,6 +1018,78 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_shade(SceneDev S, QueueDev qin, H
      qout.c[gb + k] = s_c[k];
    }
    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ trace level (fused intersect + shade)
+// The default pipeline.  One launch per trace level: the intersect stage above, then World::trace's shading of
+// each ray straight from registers, then the survivors are appended to the next level's queue.  Against the
+// split pipeline this removes the hit records (32 B written + read per ray and scan) and the second read of
+// the ray, and the remaining queue traffic hides under the scan of the other waves of the CU.
+// Compaction: a lane's R survivors wait in the park (they take the place of the slot's candidate words);
+// ballot + prefix popcount order them inside the wave and ONE global atomic per wave and loop trip (R x 64 rays)
+// reserves their slots - 4x fewer atomics than one per wave and ray row, below the ~88/us a single counter
+// sustains.
+template <int R, int NS>
+__global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(SceneDev S, QueueDev q, uint32_t* counts, uint32_t level,
+                                                           uint32_t max_depth, uint64_t pid_base, uint32_t k0,
+                                                           uint32_t k1, uint32_t role0, uint32_t role1, QueueDev qout,
+                                                           float4* radiance, PhongQueueDev pq, uint32_t* phong_counts,
+                                                           uint32_t* stats) {
+  __shared__ float park[ParkLayout<NS>::WORDS * R][CFT_BLOCK];
+  const uint32_t n = counts[level];
+  const uint32_t stride = gridDim.x * CFT_BLOCK;
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t base = blockIdx.x * CFT_BLOCK + threadIdx.x; base < n; base += stride * R) {
+    {
+      RayPack<R, NS> P;
+      isect_setup<R, NS>(S, q, n, base, stride, level, pid_base, k0, k1, role0, role1, P, park);
+      scan_lists<R, NS>(S, P);
+      isect_park<R, NS>(P, park);
+    }
+    uint32_t alive_bits = 0;
+#pragma unroll 1
+    for (int r = 0; r < R; ++r) {
+      const uint32_t i = base + r * stride;
+      if (!(i < n)) break;
+      const float4 a = q.a[i];
+      const float4 b = q.b[i];
+      const float2 c = q.c[i];
+      HitInRegisters hit;
+      isect_hit<NS>(S, r, 0, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.a0, &hit.b1);
+      hit.b0 = hit.a0;
+      if (NS == 2) isect_hit<NS>(S, r, 1, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.b0, &hit.b1);
+      f3 thr = mk3(b.z, b.w, c.x), npos, ndir;
+      const bool alive = shade_one(S, hit, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), &thr, __float_as_uint(c.y), level,
+                                   max_depth, pid_base, k0, k1, radiance, pq, phong_counts, &npos, &ndir);
+      if (alive) {   // the survivor takes over the slot's park words (path id: re-read from the queue below)
+        alive_bits |= 1u << r;
+        PARK(r, 0) = npos.x; PARK(r, 1) = npos.y; PARK(r, 2) = npos.z; PARK(r, 3) = ndir.x;
+        PARK(r, 4) = ndir.y; PARK(r, 5) = ndir.z; PARK(r, 6) = thr.x;  PARK(r, 7) = thr.y;
+        PARK(r, 8) = thr.z;
+      }
+    }
+    // append the wave's survivors: slot by slot, lanes in order
+    uint32_t total = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) total += (uint32_t)__popcll(__ballot((alive_bits >> r) & 1u));
+    if (total) {   // wave-uniform
+      const uint32_t leader = (uint32_t)__ffsll((long long)__ballot(1)) - 1u;
+      uint32_t wbase = 0;
+      if (lane == leader) wbase = atomicAdd(&counts[level + 1], total);
+      wbase = __shfl(wbase, (int)leader);
+#pragma unroll 1
+      for (int r = 0; r < R; ++r) {
+        const unsigned long long m = __ballot((alive_bits >> r) & 1u);
+        if ((alive_bits >> r) & 1u) {
+          const uint32_t o = wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+          qout.a[o] = make_float4(PARK(r, 0), PARK(r, 1), PARK(r, 2), PARK(r, 3));
+          qout.b[o] = make_float4(PARK(r, 4), PARK(r, 5), PARK(r, 6), PARK(r, 7));
+          qout.c[o] = make_float2(PARK(r, 8), q.c[base + r * stride].y);
+        }
+        wbase += (uint32_t)__popcll(m);
+      }
+    }
   }
 }
 

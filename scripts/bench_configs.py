@@ -23,7 +23,7 @@ def gpu(name, world, cam, W, H, spp, depth, reps=2):
              mrays_per_s=st.rays / st.ms_total / 1e3, intersect_ms=st.ms_intersect, shade_ms=st.ms_shade,
              shadow_ms=st.ms_shadow, intersect_tflops=st.flops_intersect / st.ms_intersect / 1e9,
              pct_fp32_peak=st.flops_intersect / st.ms_intersect / 1e9 / 157.3 * 100, levels=int(st.levels),
-             exact_second=int(st.exact_second), exact_rescan=int(st.exact_rescan), mean_rgb=[float(x) for x in acc.mean(axis=(0, 1)) / spp])
+             exact_second=int(st.exact_second), exact_rescan=int(st.exact_rescan), mean_rgb=[float(x) for x in acc.astype(np.float64).mean(axis=(0, 1)) / spp])
     print(json.dumps(r), flush=True)
     return r
 
@@ -33,7 +33,7 @@ def cpu(name, world, cam, W, H, spp, depth, threads=16):
     acc, rays = ow.render(cam.with_sample_rate(spp), W, H, depth, rt.scenes.SAMPLE_SEED, 0, spp, nthreads=threads)
     dt = time.perf_counter() - t0
     r = dict(config=name + " [CPU restatement]", size=f"{W}x{H}x{spp} depth {depth}", rays=int(rays), seconds=dt,
-             mrays_per_s=rays / dt / 1e6, threads=threads, mean_rgb=[float(x) for x in acc.mean(axis=(0, 1)) / spp])
+             mrays_per_s=rays / dt / 1e6, threads=threads, mean_rgb=[float(x) for x in acc.astype(np.float64).mean(axis=(0, 1)) / spp])
     print(json.dumps(r), flush=True)
     return r
 

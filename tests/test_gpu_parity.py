@@ -334,6 +334,38 @@ def test_determinism_and_sample_range_linearity(rt):
     assert int(st.passes) > 1 and np.allclose(c, a, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("name,W,H,spp,depth", [("s500", 320, 180, 4, 50), ("scene_rs", 160, 100, 4, 10),
+                                                 ("cornell", 80, 60, 8, 10), ("cornell_point", 80, 60, 8, 10)])
+def test_split_pipeline_matches_fused(rt, name, W, H, spp, depth):
+    """The per-level work runs either as one fused launch (default) or as k_intersect -> hit records -> k_shade;
+    both are the same code on the same rays and must give the same image bit for bit, the same ray counts and
+    the same exact-evaluation statistics.  scene_rs covers the two-scan (motion + lights) kernels, cornell the
+    light shapes, cornell_point the Phong queue and k_shadow."""
+    world, cam = (rt.scenes.cornell_rs(point_light=True) if name == "cornell_point"
+                  else getattr(rt.scenes, {"s500": "s500", "scene_rs": "scene_rs", "cornell": "cornell_rs"}[name])())
+    dev = rt.default_device()
+    a, sa = world.render(cam, W, H, depth, spp_begin=0, spp_end=spp, return_stats=True)
+    dev.set_pipeline(True)
+    try:
+        b, sb = world.render(cam, W, H, depth, spp_begin=0, spp_end=spp, return_stats=True)
+        for v in (1, 2, 4):                      # rays per lane must not matter either
+            dev.set_variant(v)
+            assert np.array_equal(world.render(cam, W, H, depth, spp_begin=0, spp_end=spp), a)
+    finally:
+        dev.set_variant(0)
+        dev.set_pipeline(False)
+    assert np.array_equal(a, b)
+    assert int(sa.rays) == int(sb.rays) and int(sa.levels) == int(sb.levels)
+    assert list(sa.rays_per_level[: int(sa.levels)]) == list(sb.rays_per_level[: int(sb.levels)])
+    assert float(sa.ms_shade) == 0.0 and float(sb.ms_shade) > 0.0
+    for v in (1, 2, 4):
+        dev.set_variant(v)
+        try:
+            assert np.array_equal(world.render(cam, W, H, depth, spp_begin=0, spp_end=spp), a)
+        finally:
+            dev.set_variant(0)
+
+
 def test_full_size_properties(rt, orc):
     """BASELINE.json configs[2] at full size (1920x1080, 64 spp, depth 50): size-independent properties."""
     world, cam = rt.scenes.s500()
