@@ -50,13 +50,13 @@ def cpu_baseline():
                       "the Rust reference, std::thread over rows)"}
 
 
-def hbm_traffic_per_launch(rays_per_step, launches_per_step):
+def hbm_traffic_per_launch(rays_per_step, launches_per_step, kernel="k_trace_level"):
     """HBM bytes per k_intersect launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled for gfx950,
     WRITE_SIZE as is; profiles/r01_hbm_traffic.json) scaled to this run's ray count; None if absent.
     PMC counters cannot be read inside the timed run."""
     path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
     try:
-        k = json.load(open(path))["kernels"]["k_intersect"]
+        k = json.load(open(path))["kernels"][kernel]
     except (OSError, KeyError, ValueError):
         return None
     return k["bytes_per_ray"] * rays_per_step / max(launches_per_step, 1)
@@ -156,14 +156,15 @@ def main():
                        "rays_per_step_per_gpu": int(s0.rays), "paths_per_step_per_gpu": int(s0.paths),
                        "trace_levels": int(s0.levels), "exact_second_evals": int(s0.exact_second),
                        "exact_rescans": int(s0.exact_rescan)},
-            "roofline": {"bound": "valu_fp32", "kernel": "k_intersect", "achieved": achieved,
+            "roofline": {"bound": "valu_fp32", "kernel": "k_intersect" if split else "k_trace_level", "achieved": achieved,
                          "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
-                         "traffic": hbm_traffic_per_launch(int(s0.rays), n_launch // max(args.steps, 1)),
+                         "traffic": hbm_traffic_per_launch(int(s0.rays), n_launch // max(args.steps, 1),
+                                                            "k_intersect" if split else "k_trace_level"),
                          "launches": n_launch, "avg_launch_ms": ms_isect / max(n_launch, 1),
                          "algorithmic_flops_per_launch": fl_isect / max(n_launch, 1),
                          "flops_per_ray": 16 * 500, "whole_loop_tflops": sum(s.flops for s in stats) / elapsed_max / 1e12},
             "kernel_ms_per_step": {"generate": sum(s.ms_generate for s in stats) / args.steps,
-                                   "intersect": ms_isect / args.steps,
+                                   ("intersect" if split else "trace_level"): ms_isect / args.steps,
                                    "shade": sum(s.ms_shade for s in stats) / args.steps,
                                    "resolve": sum(s.ms_resolve for s in stats) / args.steps,
                                    "device_total": sum(s.ms_total for s in stats) / args.steps},
