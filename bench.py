@@ -133,7 +133,9 @@ def main():
 
     if rank == 0:
         ms_isect = sum(s.ms_intersect for s in stats)
-        fl_isect = sum(s.flops_intersect for s in stats)
+        # split: the scan's flops over k_intersect's time; fused: the level kernel does scan + shading, so its
+        # algorithmic work is the whole per-ray figure of SURVEY 8d (16 Nsph + 44 Ntri + 200)
+        fl_isect = sum((s.flops_intersect if split else s.flops) for s in stats)
         n_launch = sum(int(s.launches_intersect) for s in stats)
         achieved = fl_isect / (ms_isect * 1e-3) / 1e12 if ms_isect > 0 else 0.0
         s0 = stats[-1]
@@ -162,7 +164,7 @@ def main():
                                                             "k_intersect" if split else "k_trace_level"),
                          "launches": n_launch, "avg_launch_ms": ms_isect / max(n_launch, 1),
                          "algorithmic_flops_per_launch": fl_isect / max(n_launch, 1),
-                         "flops_per_ray": 16 * 500, "whole_loop_tflops": sum(s.flops for s in stats) / elapsed_max / 1e12},
+                         "flops_per_ray": 16 * 500 + (0 if split else 200), "whole_loop_tflops": sum(s.flops for s in stats) / elapsed_max / 1e12},
             "kernel_ms_per_step": {"generate": sum(s.ms_generate for s in stats) / args.steps,
                                    ("intersect" if split else "trace_level"): ms_isect / args.steps,
                                    "shade": sum(s.ms_shade for s in stats) / args.steps,

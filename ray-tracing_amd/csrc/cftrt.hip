@@ -542,8 +542,20 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
   int R = ctx->variant ? ctx->variant : CFT_RAYS_PER_LANE;
   if (!ctx->variant && P < (1u << 20)) R = 2;
   if (two_scans && R > 2) R = 2;
-  const uint32_t g = grid_for(ctx, ((uint64_t)P + R - 1) / R, 8);
   hipStream_t st = ctx->stream;
+  if (!ctx->variant && P < (1u << 18) && !getenv("CFTRT_NO_TAIL")) {
+    // too few rays to fill the chip: the list is split over the 4 waves of a block (k_trace_tail), 128 rays per block
+    uint64_t blocks = ((uint64_t)P + 127) / 128;
+    blocks = std::max<uint64_t>(1, std::min<uint64_t>(blocks, (uint64_t)ctx->n_cu * 8));
+    if (two_scans)
+      hipLaunchKernelGGL((k_trace_tail<2, 2>), dim3((uint32_t)blocks), dim3(CFT_BLOCK), 0, st, S, q, counts, level, max_depth,
+                         pid_base, k0, k1, role0, role1, qout, rad, pq, phong_counts, xstats);
+    else
+      hipLaunchKernelGGL((k_trace_tail<2, 1>), dim3((uint32_t)blocks), dim3(CFT_BLOCK), 0, st, S, q, counts, level, max_depth,
+                         pid_base, k0, k1, role0, role1, qout, rad, pq, phong_counts, xstats);
+    return;
+  }
+  const uint32_t g = grid_for(ctx, ((uint64_t)P + R - 1) / R, 8);
 #define CFT_LAUNCH(RR, NN) hipLaunchKernelGGL((k_trace_level<RR, NN>), dim3(g), dim3(CFT_BLOCK), 0, st, S, q, counts, level, \
                                               max_depth, pid_base, k0, k1, role0, role1, qout, rad, pq, phong_counts, xstats)
   if (two_scans) {
@@ -559,11 +571,24 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
 #undef CFT_LAUNCH
 }
 
-struct EvTimer {   // pairs of events around launches on the ctx stream, summed per class after a sync
+enum { CLS_GEN = 0, CLS_ISECT, CLS_SHADE, CLS_SHADOW, CLS_RESOLVE, CLS_N };
+
+// Pairs of HIP events around launches on the ctx stream, summed per class after a sync.  An event record is a
+// packet of its own on the queue (~6 us each, 0.65 ms per S500 frame with one pair per launch), so consecutive
+// launches of the SAME class share one pair: the end event is only recorded when the class changes or the host
+// is about to wait on the stream (flush).  The fused pipeline thus times each group of levels between two
+// peeks as one span (launch-to-launch gaps of ~10 us included); the split pipeline alternates classes and keeps
+// one pair per launch.
+struct EvTimer {
   cftrt_ctx* ctx;
   size_t used = 0;
-  std::vector<std::pair<size_t, int>> spans;   // (start event index, class)
+  bool open = false;                            // the last span's end event has not been recorded yet
+  std::vector<std::pair<size_t, int>> spans;    // (start event index, class)
+  uint32_t launches[CLS_N] = {0};
   int begin(int cls) {
+    launches[cls] += 1;
+    if (open && spans.back().second == cls) return 0;
+    flush();
     if (used + 2 > ctx->events.size()) {
       size_t old = ctx->events.size();
       ctx->events.resize(old + 256);
@@ -571,24 +596,28 @@ struct EvTimer {   // pairs of events around launches on the ctx stream, summed 
         if (hipEventCreate(&ctx->events[i]) != hipSuccess) return -1;
     }
     spans.push_back({used, cls});
-    hipEventRecord(ctx->events[used], ctx->stream);
+    (void)hipEventRecord(ctx->events[used], ctx->stream);
     used += 2;
+    open = true;
     return 0;
   }
-  void end() { hipEventRecord(ctx->events[spans.back().first + 1], ctx->stream); }
-  void collect(double* ms_by_class, uint32_t* n_by_class) {
+  void end() {}
+  void flush() {
+    if (open) (void)hipEventRecord(ctx->events[spans.back().first + 1], ctx->stream);
+    open = false;
+  }
+  void collect(double* ms_by_class, uint32_t* n_by_class) {   // after a stream sync
+    flush();
+    (void)hipStreamSynchronize(ctx->stream);
     for (auto& sp : spans) {
       float ms = 0.f;
-      if (hipEventElapsedTime(&ms, ctx->events[sp.first], ctx->events[sp.first + 1]) == hipSuccess) {
-        ms_by_class[sp.second] += ms;
-        n_by_class[sp.second] += 1;
-      }
+      if (hipEventElapsedTime(&ms, ctx->events[sp.first], ctx->events[sp.first + 1]) == hipSuccess) ms_by_class[sp.second] += ms;
     }
+    for (int c = 0; c < CLS_N; ++c) { n_by_class[c] += launches[c]; launches[c] = 0; }
     spans.clear();
     used = 0;
   }
 };
-enum { CLS_GEN = 0, CLS_ISECT, CLS_SHADE, CLS_SHADOW, CLS_RESOLVE, CLS_N };
 
 // Renders path ids [pid_base, pid_base + P) (P = npix * nsamples) into the radiance buffer and, when
 // accum_dev != null, resolves them into accum_dev.
@@ -665,6 +694,7 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
     levels_run = level + 1;
     // every 4 levels look at the next level's count; stop when the queue has drained
     if ((level & 3) == 3 && level + 1 < max_depth) {
+      tm.flush();
       HIP_TRY(ctx, hipMemcpyAsync(ctx->host_counts, counts + level + 1, 4, hipMemcpyDeviceToHost, st_));
       HIP_TRY(ctx, hipStreamSynchronize(st_));
       if (ctx->host_counts[0] == 0) break;
@@ -676,6 +706,7 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
     hipLaunchKernelGGL(k_resolve, dim3(grid_for(ctx, npix, 16)), dim3(CFT_BLOCK), 0, st_, rad, npix, nsamples, accum_dev);
     tm.end();
   }
+  tm.flush();
   HIP_TRY(ctx, hipMemcpyAsync(ctx->host_counts, counts, ncount * 4, hipMemcpyDeviceToHost, st_));
   HIP_TRY(ctx, hipStreamSynchronize(st_));
   HIP_TRY(ctx, hipGetLastError());

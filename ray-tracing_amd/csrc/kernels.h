@@ -364,17 +364,19 @@ typedef float v8f __attribute__((ext_vector_type(8)));
 typedef const v8f __attribute__((address_space(4))) * c_f8p;
 
 // f32 scan of every non-precise primitive for R rays (indices into [sphF | msph | triF | mtri]).
+// part / nparts (wave-uniform): this wave scans the part-th slice of each list (nparts = 1: all of it).
 template <int R, int NS>
-__device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P) {
+__device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P, int part = 0, int nparts = 1) {
   {
     // 4 spheres per s_load_dwordx16 (+ their r^2 in one s_load_dwordx4), fetched one batch ahead; both
     // arrays are padded on the host with never-hit spheres (k4 = +1e30) to a multiple of 4 plus one batch.
     c_f16p sp = AS_CONST(c_f16p, S.sphF);
     c_f4p rp = AS_CONST(c_f4p, S.sphR2);
     const int n4 = (S.n_sphF + 3) >> 2;
-    v16f cur = sp[0];
-    v4f cr = rp[0];
-    for (int s4 = 0; s4 < n4; ++s4) {
+    const int lo4 = n4 * part / nparts, hi4 = n4 * (part + 1) / nparts;
+    v16f cur = sp[lo4];
+    v4f cr = rp[lo4];
+    for (int s4 = lo4; s4 < hi4; ++s4) {
       v16f nxt = sp[s4 + 1];
       v4f nr = rp[s4 + 1];
       const int s = s4 << 2;
@@ -391,9 +393,10 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P)
     // moving spheres, 8 floats each: (cx, cy, cz, r^2, mvx, mvy, mvz, object id); centre + time * moving_to
     // with one fresh time per object per scan (object.rs:42-55)
     c_f8p sp = AS_CONST(c_f8p, S.msphF);
-    const int n = S.n_msph;
-    v8f cur = sp[0];
-    for (int s = 0; s < n; ++s) {
+    const int n = S.n_msph * (part + 1) / nparts;
+    const int lo = S.n_msph * part / nparts;
+    v8f cur = sp[lo];
+    for (int s = lo; s < n; ++s) {
       v8f nxt = sp[s + 1];   // padded by one entry on the host
       const uint32_t obj = __float_as_uint(cur[7]);
 #pragma unroll
@@ -419,8 +422,8 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P)
   base += S.n_msph;
   {
     c_f4p tp = AS_CONST(c_f4p, S.triF);
-    const int n = S.n_triF;
-    for (int s = 0; s < n; ++s) {
+    const int n = S.n_triF * (part + 1) / nparts;
+    for (int s = S.n_triF * part / nparts; s < n; ++s) {
       v4f a = tp[3 * s], b = tp[3 * s + 1], cc = tp[3 * s + 2];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -437,7 +440,7 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P)
   base += S.n_triF;
   if (S.n_mtri) {   // moving triangles, 4 float4 each: p0, e1, e2, (mv, object id)
     c_f4p tp = AS_CONST(c_f4p, S.mtriF);
-    for (int s = 0; s < S.n_mtri; ++s) {
+    for (int s = S.n_mtri * part / nparts; s < S.n_mtri * (part + 1) / nparts; ++s) {
       v4f a = tp[4 * s], b = tp[4 * s + 1], cc = tp[4 * s + 2], m = tp[4 * s + 3];
       const uint32_t obj = __float_as_uint(m.w);
 #pragma unroll
@@ -1070,6 +1073,107 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(SceneDev S, QueueD
       }
     }
     // append the wave's survivors: slot by slot, lanes in order
+    uint32_t total = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) total += (uint32_t)__popcll(__ballot((alive_bits >> r) & 1u));
+    if (total) {   // wave-uniform
+      const uint32_t leader = (uint32_t)__ffsll((long long)__ballot(1)) - 1u;
+      uint32_t wbase = 0;
+      if (lane == leader) wbase = atomicAdd(&counts[level + 1], total);
+      wbase = __shfl(wbase, (int)leader);
+#pragma unroll 1
+      for (int r = 0; r < R; ++r) {
+        const unsigned long long m = __ballot((alive_bits >> r) & 1u);
+        if ((alive_bits >> r) & 1u) {
+          const uint32_t o = wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+          qout.a[o] = make_float4(PARK(r, 0), PARK(r, 1), PARK(r, 2), PARK(r, 3));
+          qout.b[o] = make_float4(PARK(r, 4), PARK(r, 5), PARK(r, 6), PARK(r, 7));
+          qout.c[o] = make_float2(PARK(r, 8), q.c[base + r * stride].y);
+        }
+        wbase += (uint32_t)__popcll(m);
+      }
+    }
+  }
+}
+
+// The same level step for launches that cannot fill the chip (the deep levels: 16 k - 300 k live rays against
+// 65 k lanes x 4+ waves).  There the launch time is ONE wave's latency through the list, so the list is split
+// over the four waves of a block: all four take the same 64 x R rays, each scans a quarter of every list, the
+// candidate sets meet in the LDS park (a wave's top three bounds, merged best-two-first so that a third bound
+// never displaces an indexed one on a tie), and wave 0 finishes, shades and appends as usual.
+template <int R, int NS>
+__global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_tail(SceneDev S, QueueDev q, uint32_t* counts, uint32_t level,
+                                                          uint32_t max_depth, uint64_t pid_base, uint32_t k0,
+                                                          uint32_t k1, uint32_t role0, uint32_t role1, QueueDev qout,
+                                                          float4* radiance, PhongQueueDev pq, uint32_t* phong_counts,
+                                                          uint32_t* stats) {
+  __shared__ float park[ParkLayout<NS>::WORDS * R][CFT_BLOCK];
+  const uint32_t n = counts[level];
+  const uint32_t lane = threadIdx.x & 63u;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t stride = gridDim.x * 64u;
+  for (uint32_t base = blockIdx.x * 64u + lane; base < n; base += stride * R) {
+    {
+      RayPack<R, NS> P;
+      isect_setup<R, NS>(S, q, n, base, stride, level, pid_base, k0, k1, role0, role1, P, park);
+      scan_lists<R, NS>(S, P, wave, CFT_BLOCK / 64);
+      isect_park<R, NS>(P, park);
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+          Cand c;
+          c.lo1 = PARK(r, ParkLayout<NS>::CAND + 5 * k + 0);
+          c.lo2 = PARK(r, ParkLayout<NS>::CAND + 5 * k + 1);
+          c.lo3 = PARK(r, ParkLayout<NS>::CAND + 5 * k + 2);
+          c.i1 = __float_as_int(PARK(r, ParkLayout<NS>::CAND + 5 * k + 3));
+          c.i2 = __float_as_int(PARK(r, ParkLayout<NS>::CAND + 5 * k + 4));
+#pragma unroll
+          for (int w = 1; w < CFT_BLOCK / 64; ++w) {
+            float (*col)[CFT_BLOCK] = park;   // the other wave's column: same lane, thread index + 64 w
+            const int t = (int)threadIdx.x + 64 * w;
+            const int j = r * ParkLayout<NS>::WORDS + ParkLayout<NS>::CAND + 5 * k;
+            const float l1 = col[j + 0][t], l2 = col[j + 1][t], l3 = col[j + 2][t];
+            const int i1 = __float_as_int(col[j + 3][t]), i2 = __float_as_int(col[j + 4][t]);
+            if (i1 >= 0) cand_insert(c, l1, i1);
+            if (i2 >= 0) cand_insert(c, l2, i2);
+            if (l3 < __builtin_inff()) cand_insert(c, l3, -1);   // lands third at best: two bounds <= it went in first
+          }
+          PARK(r, ParkLayout<NS>::CAND + 5 * k + 0) = c.lo1;
+          PARK(r, ParkLayout<NS>::CAND + 5 * k + 1) = c.lo2;
+          PARK(r, ParkLayout<NS>::CAND + 5 * k + 2) = c.lo3;
+          PARK(r, ParkLayout<NS>::CAND + 5 * k + 3) = __int_as_float(c.i1);
+          PARK(r, ParkLayout<NS>::CAND + 5 * k + 4) = __int_as_float(c.i2);
+        }
+      }
+    }
+    __syncthreads();   // the other waves may overwrite their columns only after the merge
+    if (wave != 0) continue;
+    uint32_t alive_bits = 0;
+#pragma unroll 1
+    for (int r = 0; r < R; ++r) {
+      const uint32_t i = base + r * stride;
+      if (!(i < n)) break;
+      const float4 a = q.a[i];
+      const float4 b = q.b[i];
+      const float2 c = q.c[i];
+      HitInRegisters hit;
+      isect_hit<NS>(S, r, 0, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.a0, &hit.b1);
+      hit.b0 = hit.a0;
+      if (NS == 2) isect_hit<NS>(S, r, 1, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.b0, &hit.b1);
+      f3 thr = mk3(b.z, b.w, c.x), npos, ndir;
+      const bool alive = shade_one(S, hit, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), &thr, __float_as_uint(c.y), level,
+                                   max_depth, pid_base, k0, k1, radiance, pq, phong_counts, &npos, &ndir);
+      if (alive) {
+        alive_bits |= 1u << r;
+        PARK(r, 0) = npos.x; PARK(r, 1) = npos.y; PARK(r, 2) = npos.z; PARK(r, 3) = ndir.x;
+        PARK(r, 4) = ndir.y; PARK(r, 5) = ndir.z; PARK(r, 6) = thr.x;  PARK(r, 7) = thr.y;
+        PARK(r, 8) = thr.z;
+      }
+    }
     uint32_t total = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) total += (uint32_t)__popcll(__ballot((alive_bits >> r) & 1u));

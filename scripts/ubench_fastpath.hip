@@ -315,7 +315,7 @@ template <typename F> float time_ms(F f, int reps) {
 }
 
 int main(int argc, char** argv) {
-  const uint32_t N = 1u << 23;
+  const uint32_t N = argc > 2 ? (uint32_t)atoi(argv[2]) : 1u << 23;   // small N: one wave's latency through the list
   const int NS = 500;
   int bpc = argc > 1 ? atoi(argv[1]) : 4;
   std::vector<float> scene, never, r2;
@@ -335,7 +335,9 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&d_never, never.size() * 4)); CK(hipMemcpy(d_never, never.data(), never.size() * 4, hipMemcpyHostToDevice));
   CK(hipMalloc(&d_r2, r2.size() * 4)); CK(hipMemcpy(d_r2, r2.data(), r2.size() * 4, hipMemcpyHostToDevice));
   CK(hipMalloc(&d_out, 8)); CK(hipMemset(d_out, 0, 8));
-  const int grid = 256 * bpc, n4 = NS / 4;
+  const int n4 = NS / 4;
+  int grid = 256 * bpc;
+  if ((uint32_t)grid * 256u > N) grid = (int)((N + 255) / 256);
   printf("rays %u spheres %d blocks/CU %d\n", N, NS, bpc);
   struct V { const char* name; void (*k)(const float*, const float*, int, uint32_t, uint32_t*); int R; } vs[] = {
     {"N1 no branch", k_scan<1, 0>, 1}, {"N2 no branch", k_scan<2, 0>, 2}, {"N4 no branch", k_scan<4, 0>, 4},
