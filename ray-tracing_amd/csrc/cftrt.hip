@@ -543,7 +543,8 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
   if (!ctx->variant && P < (1u << 20)) R = 2;
   if (two_scans && R > 2) R = 2;
   hipStream_t st = ctx->stream;
-  if (!ctx->variant && P < (1u << 18) && !getenv("CFTRT_NO_TAIL")) {
+  static const uint32_t tail_below = getenv("CFTRT_TAIL_BELOW") ? (uint32_t)atol(getenv("CFTRT_TAIL_BELOW")) : (1u << 19);   // measured optimum on S500 (2^18..2^20 within 1 %)
+  if (!ctx->variant && P < tail_below) {
     // too few rays to fill the chip: the list is split over the 4 waves of a block (k_trace_tail), 128 rays per block
     uint64_t blocks = ((uint64_t)P + 127) / 128;
     blocks = std::max<uint64_t>(1, std::min<uint64_t>(blocks, (uint64_t)ctx->n_cu * 8));
@@ -692,8 +693,9 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
       tm.end();
     }
     levels_run = level + 1;
-    // every 4 levels look at the next level's count; stop when the queue has drained
-    if ((level & 3) == 3 && level + 1 < max_depth) {
+    // every 4 levels (every 16 once the launches are latency-bound: a peek idles the GPU for ~35 us) look at the
+    // next level's count; stop when the queue has drained
+    if ((level & (ub < (1u << 19) ? 15u : 3u)) == 3u && level + 1 < max_depth) {
       tm.flush();
       HIP_TRY(ctx, hipMemcpyAsync(ctx->host_counts, counts + level + 1, 4, hipMemcpyDeviceToHost, st_));
       HIP_TRY(ctx, hipStreamSynchronize(st_));
