@@ -663,7 +663,8 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
   float4* rad = (float4*)ctx->rad.p;
 
   if (tm.begin(CLS_GEN)) return fail(ctx, CFTRT_ERR_HIP, "hipEventCreate failed");
-  hipLaunchKernelGGL(k_generate, dim3(grid_for(ctx, P, 16)), dim3(CFT_BLOCK), 0, st_, C, pid_base, P, k0, k1, jitter, q[0]);
+  const int tiled = (C.width % 32u == 0 && C.height % 8u == 0 && npix == C.width * C.height && P % npix == 0 && pid_base % npix == 0) ? 1 : 0;
+  hipLaunchKernelGGL(k_generate, dim3(grid_for(ctx, P, 16)), dim3(CFT_BLOCK), 0, st_, C, pid_base, P, k0, k1, jitter, tiled, q[0]);
   tm.end();
 
   uint32_t ub = P;   // upper bound on the live rays of the current level (a ray spawns at most one ray)
@@ -817,7 +818,7 @@ int cftrt_generate(cftrt_ctx* ctx, const cftrt_camera* cam, uint32_t width, uint
   if ((rc = ensure(ctx, ctx->qa[0], n * 16)) || (rc = ensure(ctx, ctx->qb[0], n * 16)) || (rc = ensure(ctx, ctx->qc[0], n * 8))) return rc;
   QueueDev q{(float4*)ctx->qa[0].p, (float4*)ctx->qb[0].p, (float2*)ctx->qc[0].p};
   hipLaunchKernelGGL(k_generate, dim3(grid_for(ctx, n, 16)), dim3(CFT_BLOCK), 0, ctx->stream, C, pid0, (uint32_t)n,
-                     (uint32_t)seed, (uint32_t)(seed >> 32), jitter, q);
+                     (uint32_t)seed, (uint32_t)(seed >> 32), jitter, 0, q);
   std::vector<float4> a(n), b(n);
   HIP_TRY(ctx, hipMemcpyAsync(a.data(), q.a, n * 16, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(b.data(), q.b, n * 16, hipMemcpyDeviceToHost, ctx->stream));

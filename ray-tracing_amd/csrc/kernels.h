@@ -584,15 +584,27 @@ __device__ __forceinline__ void primary_ray(const CamDev& C, uint64_t pid, uint3
   *dir = unit3(to - from);   // Ray::new normalises (ray.rs:30-35)
 }
 
-// one lane = one (pixel, sample): local path id i -> global pid = pid_base + i
+// one lane = one (pixel, sample).  Queue slot i holds local path id lp (global pid = pid_base + lp).  With
+// `tiled` (whole samples of an image whose width is a multiple of 32 and height of 8) the slots of a sample run
+// through 32x8-pixel tiles, so that the 256 (or 128) consecutive slots a wave of the level kernels takes are a
+// compact pixel block: their primary rays form a narrow bundle, which the wave-level cull (wave_bundle) uses.
+// Otherwise lp = i (row-major).  The order of the queue never affects the image: radiance is stored by lp.
 __global__ __launch_bounds__(CFT_BLOCK) void k_generate(CamDev C, uint64_t pid_base, uint32_t n, uint32_t k0,
-                                                        uint32_t k1, int jitter, QueueDev q) {
+                                                        uint32_t k1, int jitter, int tiled, QueueDev q) {
+  const uint32_t npix = C.width * C.height;
   for (uint32_t i = blockIdx.x * CFT_BLOCK + threadIdx.x; i < n; i += gridDim.x * CFT_BLOCK) {
+    uint32_t lp = i;
+    if (tiled) {
+      const uint32_t smp = i / npix, j = i - smp * npix;
+      const uint32_t t = j >> 8, wi = j & 255u, ntx = C.width >> 5;
+      const uint32_t ty = t / ntx, tx = t - ty * ntx;
+      lp = smp * npix + (ty * 8u + (wi >> 5)) * C.width + tx * 32u + (wi & 31u);
+    }
     f3 pos, dir;
-    primary_ray(C, pid_base + i, k0, k1, jitter, &pos, &dir);
+    primary_ray(C, pid_base + lp, k0, k1, jitter, &pos, &dir);
     q.a[i] = make_float4(pos.x, pos.y, pos.z, dir.x);
     q.b[i] = make_float4(dir.y, dir.z, 1.0f, 1.0f);
-    q.c[i] = make_float2(1.0f, __uint_as_float(i));
+    q.c[i] = make_float2(1.0f, __uint_as_float(lp));
   }
 }
 
@@ -736,8 +748,12 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_intersect(SceneDev S, QueueDev q,
                                                          HitDev out1, uint32_t* stats) {
   __shared__ float park[ParkLayout<NS>::WORDS * R][CFT_BLOCK];
   const uint32_t n = counts[level];
-  const uint32_t stride = gridDim.x * CFT_BLOCK;
-  for (uint32_t base = blockIdx.x * CFT_BLOCK + threadIdx.x; base < n; base += stride * R) {
+  // a wave takes 64 R consecutive queue slots (slot r of lane l = wave base + 64 r + l); the trip count is
+  // wave-uniform so that every lane stays active for the wave-level cull
+  const uint32_t stride = 64u;
+  const uint32_t wstep = gridDim.x * CFT_BLOCK * R;
+  for (uint32_t wb = (blockIdx.x * CFT_BLOCK + (threadIdx.x & ~63u)) * R; wb < n; wb += wstep) {
+    const uint32_t base = wb + (threadIdx.x & 63u);
     {
       RayPack<R, NS> P;
       isect_setup<R, NS>(S, q, n, base, stride, level, pid_base, k0, k1, role0, role1, P, park);
@@ -1041,9 +1057,11 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(SceneDev S, QueueD
                                                            uint32_t* stats) {
   __shared__ float park[ParkLayout<NS>::WORDS * R][CFT_BLOCK];
   const uint32_t n = counts[level];
-  const uint32_t stride = gridDim.x * CFT_BLOCK;
+  const uint32_t stride = 64u;   // wave-contiguous slots, wave-uniform trip count (see k_intersect)
+  const uint32_t wstep = gridDim.x * CFT_BLOCK * R;
   const uint32_t lane = threadIdx.x & 63u;
-  for (uint32_t base = blockIdx.x * CFT_BLOCK + threadIdx.x; base < n; base += stride * R) {
+  for (uint32_t wb = (blockIdx.x * CFT_BLOCK + (threadIdx.x & ~63u)) * R; wb < n; wb += wstep) {
+    const uint32_t base = wb + lane;
     {
       RayPack<R, NS> P;
       isect_setup<R, NS>(S, q, n, base, stride, level, pid_base, k0, k1, role0, role1, P, park);
@@ -1111,8 +1129,9 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_tail(SceneDev S, QueueDe
   const uint32_t n = counts[level];
   const uint32_t lane = threadIdx.x & 63u;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint32_t stride = gridDim.x * 64u;
-  for (uint32_t base = blockIdx.x * 64u + lane; base < n; base += stride * R) {
+  const uint32_t stride = 64u;
+  for (uint32_t wb = blockIdx.x * 64u * R; wb < n; wb += gridDim.x * 64u * R) {   // block-uniform: barriers inside
+    const uint32_t base = wb + lane;
     {
       RayPack<R, NS> P;
       isect_setup<R, NS>(S, q, n, base, stride, level, pid_base, k0, k1, role0, role1, P, park);
