@@ -96,6 +96,8 @@ def main():
         dev.set_variant(int(os.environ["CFTRT_VARIANT"]))
     split = os.environ.get("CFTRT_PIPELINE", "fused") == "split"   # profiling aid: the two stages as separate kernels
     dev.set_pipeline(split)
+    if os.environ.get("CFTRT_WAVE_CULL"):
+        dev.set_wave_cull(int(os.environ["CFTRT_WAVE_CULL"]))   # 0: plain linear scan, for profiling
     scene.commit(dev)
     accum = torch.zeros(H * W * 3, dtype=torch.float32, device=f"cuda:{local_rank}")
     spp_begin, spp_end = rank * spp, (rank + 1) * spp

@@ -121,6 +121,10 @@ int cftrt_ctx_set_workspace_limit(cftrt_ctx* ctx, uint64_t bytes);
  * Both produce the same image bit for bit.  In fused mode cftrt_stats.ms_intersect / flops_intersect /
  * launches_intersect describe the fused kernel and ms_shade is 0. */
 int cftrt_ctx_set_pipeline(cftrt_ctx* ctx, int split);
+/* Wave-level cull (default on): the level kernels skip spheres that no ray of a wave's 64-256 ray bundle can
+ * reach (a conservative cone test per sphere and wave) before the per-ray cull.  Results are identical with it
+ * off; the switch exists for that comparison (tests) and for profiling the plain linear scan. */
+int cftrt_ctx_set_wave_cull(cftrt_ctx* ctx, int on);
 /* Intersect-kernel variant: rays per lane of k_intersect / k_trace_level (1..4); 0 = the tuned default. */
 int cftrt_ctx_set_variant(cftrt_ctx* ctx, int variant);
 

@@ -353,6 +353,10 @@ class Device:
         """False/0 = fused k_trace_level per level (default), True/1 = k_intersect + k_shade with hit records."""
         self.check(self.lib.cftrt_ctx_set_pipeline(self.h, int(bool(split))))
 
+    def set_wave_cull(self, on):
+        """Wave-level sphere cull of the level kernels (default on); images are identical either way."""
+        self.check(self.lib.cftrt_ctx_set_wave_cull(self.h, int(bool(on))))
+
     def set_variant(self, v):
         self.check(self.lib.cftrt_ctx_set_variant(self.h, int(v)))
 

@@ -23,6 +23,7 @@ struct cftrt_ctx {
   std::string err;
   uint64_t ws_limit = 40ull << 30;
   int variant = 0;
+  int wave_cull = 1;      // level kernels may skip spheres no ray of a wave's bundle can reach (exact either way)
   int split = 0;          // 0: fused k_trace_level per level (default); 1: k_intersect -> hit records -> k_shade
   int n_cu = 256;
   // grow-only workspace
@@ -158,6 +159,12 @@ int cftrt_ctx_set_workspace_limit(cftrt_ctx* ctx, uint64_t bytes) {
   if (!ctx) return CFTRT_ERR_INVALID;
   if (bytes < (64ull << 20)) return fail(ctx, CFTRT_ERR_LIMIT, "workspace limit below 64 MiB");
   ctx->ws_limit = bytes;
+  return CFTRT_OK;
+}
+
+int cftrt_ctx_set_wave_cull(cftrt_ctx* ctx, int on) {
+  if (!ctx) return CFTRT_ERR_INVALID;
+  ctx->wave_cull = on ? 1 : 0;
   return CFTRT_OK;
 }
 
@@ -625,7 +632,8 @@ struct EvTimer {
 static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t P, uint32_t nsamples, uint32_t npix,
                     uint32_t max_depth, uint64_t seed, int jitter, float* accum_dev, cftrt_stats* st, EvTimer& tm) {
   cftrt_ctx* ctx = s->ctx;
-  const SceneDev& S = s->dev;
+  SceneDev S = s->dev;
+  S.wave_cull = ctx->wave_cull;
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
   const bool phong = S.n_phong_mats > 0;
   const bool two_scans = S.any_motion && S.n_lights > 0;   // `looked` and trace each draw their own motion times

@@ -363,17 +363,85 @@ __device__ __forceinline__ void scan_sphere(const SceneDev& S, RayPack<R, NS>& P
 typedef float v8f __attribute__((ext_vector_type(8)));
 typedef const v8f __attribute__((address_space(4))) * c_f8p;
 
+// Wave-level cull.  The 64 R rays of a wave often form a narrow bundle (primary rays of a pixel tile, mirror
+// and refraction rays of neighbouring pixels): origins within rho of a reference origin, directions within an
+// angle theta of a reference axis.  A ray of the bundle can only hit sphere (c, r) if the ray from the reference
+// origin with the same direction hits the sphere inflated by rho, i.e. if angle(c - o_ref, axis) <= theta +
+// asin(R'/L), R' = r + rho, L = |c - o_ref|:
+//     v.a >= cos(theta) sqrt(L^2 - R'^2) - sin(theta) R'        (or L <= R')
+// Lanes test 64 spheres at a time against that cone (vector loads, one lane per sphere), the ballot is walked
+// bit by bit and only those spheres reach the per-ray cull.  Conservative by construction plus slack far above
+// f32 rounding (0.1 % on R', 1e-5 (1 + L) absolute); `wave_cull` in the tests compares images with it off.
+// Returns false (nothing done) when the bundle is wider than ~37 degrees: the caller scans the whole list.
+template <int R, int NS>
+__device__ __forceinline__ bool scan_spheres_culled(const SceneDev& S, RayPack<R, NS>& P, int lo, int hi) {
+  const float inf = __builtin_inff();
+  const unsigned long long v0 = __builtin_amdgcn_ballot_w64(PK(P, thr4, 0) < inf);   // slot 0 fills first
+  if (v0 == 0ull) return true;                                                        // no live ray in this wave
+  const int lead = (int)__builtin_ctzll(v0);
+#define CFT_RL(x) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lead))
+  const float rox = 0.25f * CFT_RL(PK(P, o4x, 0)), roy = 0.25f * CFT_RL(PK(P, o4y, 0)), roz = 0.25f * CFT_RL(PK(P, o4z, 0));
+  const float ax = CFT_RL(PK(P, dx, 0)), ay = CFT_RL(PK(P, dy, 0)), az = CFT_RL(PK(P, dz, 0));
+#undef CFT_RL
+  float d2max = 0.0f, cmin = 1.0f;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (PK(P, thr4, r) < inf) {
+      const float ex = fmaf(0.25f, PK(P, o4x, r), -rox), ey = fmaf(0.25f, PK(P, o4y, r), -roy), ez = fmaf(0.25f, PK(P, o4z, r), -roz);
+      d2max = fmaxf(d2max, fmaf(ez, ez, fmaf(ey, ey, ex * ex)));
+      cmin = fminf(cmin, fmaf(PK(P, dz, r), az, fmaf(PK(P, dy, r), ay, PK(P, dx, r) * ax)));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    d2max = fmaxf(d2max, __shfl_xor(d2max, o));
+    cmin = fminf(cmin, __shfl_xor(cmin, o));
+  }
+  const float cth = cmin - 4e-6f;                      // directions are unit to a few ulp
+  if (!(cth > 0.8f)) return false;
+  const float sth = sqrtf(fmaxf(1.0f - cth * cth, 0.0f)) * 1.0001f + 1e-6f;
+  const float rho = sqrtf(d2max) * 1.0001f;
+  const int lane = (int)(threadIdx.x & 63u);
+  for (int s0 = lo; s0 < hi; s0 += 64) {
+    const int idx = s0 + lane;
+    bool pass = false;
+    if (idx < hi) {
+      const float4 sp = S.sphF[idx];
+      const float r = 0.25f * sqrtf(S.sphR2[idx]);
+      const float vx = fmaf(-0.5f, sp.x, -rox), vy = fmaf(-0.5f, sp.y, -roy), vz = fmaf(-0.5f, sp.z, -roz);
+      const float L2 = fmaf(vz, vz, fmaf(vy, vy, vx * vx));
+      const float va = fmaf(vz, az, fmaf(vy, ay, vx * ax));
+      const float slack = 1e-5f * (1.0f + sqrtf(L2));
+      const float Rp = (r + rho) * 1.001f + slack;
+      const float h2 = fmaf(-Rp, Rp, L2);
+      pass = h2 <= 0.0f || va >= cth * sqrtf(fmaxf(h2, 0.0f)) - sth * Rp - slack;
+    }
+    unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+    while (m) {
+      const int id = s0 + (int)__builtin_ctzll(m);
+      m &= m - 1ull;
+      const v4f sp = AS_CONST(c_f4p, S.sphF)[id];
+      const float r2x16 = AS_CONST(c_f32p, S.sphR2)[id];
+      scan_sphere<R, NS>(S, P, v2f{sp[0], sp[1]}, v2f{sp[2], sp[3]}, r2x16, id);
+    }
+  }
+  return true;
+}
+
 // f32 scan of every non-precise primitive for R rays (indices into [sphF | msph | triF | mtri]).
 // part / nparts (wave-uniform): this wave scans the part-th slice of each list (nparts = 1: all of it).
-template <int R, int NS>
+// WCULL: try the wave-level cull first (the R-rays-per-lane kernels; every lane of the wave must be active).
+template <int R, int NS, bool WCULL = false>
 __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P, int part = 0, int nparts = 1) {
-  {
+  const int n4_all = (S.n_sphF + 3) >> 2;
+  const int lo4 = n4_all * part / nparts, hi4 = n4_all * (part + 1) / nparts;
+  bool done = false;
+  if (WCULL && S.wave_cull) done = scan_spheres_culled<R, NS>(S, P, lo4 << 2, min(hi4 << 2, S.n_sphF));
+  if (!done) {
     // 4 spheres per s_load_dwordx16 (+ their r^2 in one s_load_dwordx4), fetched one batch ahead; both
     // arrays are padded on the host with never-hit spheres (k4 = +1e30) to a multiple of 4 plus one batch.
     c_f16p sp = AS_CONST(c_f16p, S.sphF);
     c_f4p rp = AS_CONST(c_f4p, S.sphR2);
-    const int n4 = (S.n_sphF + 3) >> 2;
-    const int lo4 = n4 * part / nparts, hi4 = n4 * (part + 1) / nparts;
     v16f cur = sp[lo4];
     v4f cr = rp[lo4];
     for (int s4 = lo4; s4 < hi4; ++s4) {
@@ -757,7 +825,7 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_intersect(SceneDev S, QueueDev q,
     {
       RayPack<R, NS> P;
       isect_setup<R, NS>(S, q, n, base, stride, level, pid_base, k0, k1, role0, role1, P, park);
-      scan_lists<R, NS>(S, P);
+      scan_lists<R, NS, true>(S, P);
       isect_park<R, NS>(P, park);
     }
 #pragma unroll 1
@@ -1065,7 +1133,7 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(SceneDev S, QueueD
     {
       RayPack<R, NS> P;
       isect_setup<R, NS>(S, q, n, base, stride, level, pid_base, k0, k1, role0, role1, P, park);
-      scan_lists<R, NS>(S, P);
+      scan_lists<R, NS, true>(S, P);
       isect_park<R, NS>(P, park);
     }
     uint32_t alive_bits = 0;
@@ -1135,7 +1203,7 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_tail(SceneDev S, QueueDe
     {
       RayPack<R, NS> P;
       isect_setup<R, NS>(S, q, n, base, stride, level, pid_base, k0, k1, role0, role1, P, park);
-      scan_lists<R, NS>(S, P, wave, CFT_BLOCK / 64);
+      scan_lists<R, NS, true>(S, P, wave, CFT_BLOCK / 64);
       isect_park<R, NS>(P, park);
     }
     __syncthreads();

@@ -57,6 +57,7 @@ struct SceneDev {
   int n_lights;
   const double* lsphD;    // light-shape spheres, 4 each
   const double* ltriD;    // light-shape triangles, 9 each
+  int wave_cull;          // 1: the level kernels may cull spheres per wave (cftrt_ctx_set_wave_cull)
   int any_motion;
   int prec_motion;        // some precise sphere moves
   int n_phong_mats;

@@ -366,6 +366,25 @@ def test_split_pipeline_matches_fused(rt, name, W, H, spp, depth):
             dev.set_variant(0)
 
 
+@pytest.mark.parametrize("name,W,H,spp,depth", [("s500", 640, 360, 4, 50), ("s500", 96, 54, 8, 50), ("scene_rs", 320, 200, 4, 10),
+                                                 ("cornell", 160, 120, 8, 10), ("s20k", 320, 184, 2, 8)])
+def test_wave_cull_is_exact(rt, name, W, H, spp, depth):
+    """The level kernels skip spheres that no ray of a wave's bundle can reach (cone test per sphere and wave).
+    The test is conservative, so switching it off must not change a single bit of the image or a ray count -
+    a sphere wrongly culled would lose a hit somewhere in these 0.2-1 M primary rays and their bounces.  640x360
+    and 320x184 are multiples of 32x8 (tiled queue order, narrow primary bundles); 96x54 is not (row-major)."""
+    world, cam = getattr(rt.scenes, {"s500": "s500", "scene_rs": "scene_rs", "cornell": "cornell_rs", "s20k": "s20k"}[name])()
+    dev = rt.default_device()
+    a, sa = world.render(cam, W, H, depth, spp_begin=0, spp_end=spp, return_stats=True)
+    dev.set_wave_cull(False)
+    try:
+        b, sb = world.render(cam, W, H, depth, spp_begin=0, spp_end=spp, return_stats=True)
+    finally:
+        dev.set_wave_cull(True)
+    assert np.array_equal(a, b)
+    assert list(sa.rays_per_level[: int(sa.levels)]) == list(sb.rays_per_level[: int(sb.levels)])
+
+
 def test_full_size_properties(rt, orc):
     """BASELINE.json configs[2] at full size (1920x1080, 64 spp, depth 50): size-independent properties."""
     world, cam = rt.scenes.s500()
