@@ -360,8 +360,6 @@ __device__ __forceinline__ void scan_sphere(const SceneDev& S, RayPack<R, NS>& P
   }
 }
 
-typedef float v8f __attribute__((ext_vector_type(8)));
-typedef const v8f __attribute__((address_space(4))) * c_f8p;
 
 // Wave-level cull.  The 64 R rays of a wave often form a narrow bundle (primary rays of a pixel tile, mirror
 // and refraction rays of neighbouring pixels): origins within rho of a reference origin, directions within an
@@ -373,23 +371,37 @@ typedef const v8f __attribute__((address_space(4))) * c_f8p;
 // bit by bit and only those spheres reach the per-ray cull.  Conservative by construction plus slack far above
 // f32 rounding (0.1 % on R', 1e-5 (1 + L) absolute); `wave_cull` in the tests compares images with it off.
 // Returns false (nothing done) when the bundle is wider than ~37 degrees: the caller scans the whole list.
+typedef float v8f __attribute__((ext_vector_type(8)));
+typedef const v8f __attribute__((address_space(4))) * c_f8p;
+
+struct Bundle {
+  float rox, roy, roz;   // reference origin (relative to the scene centre)
+  float ax, ay, az;      // reference axis (a ray direction, unit)
+  float cth, sth, rho;   // cos / sin of the half-angle (widened), radius of the origins around the reference
+  bool live, narrow;     // any live ray in the wave; narrow enough for the cull to pay (< ~37 degrees)
+};
+
 template <int R, int NS>
-__device__ __forceinline__ bool scan_spheres_culled(const SceneDev& S, RayPack<R, NS>& P, int lo, int hi) {
+__device__ __forceinline__ Bundle wave_bundle(const RayPack<R, NS>& P) {
+  Bundle B;
   const float inf = __builtin_inff();
   const unsigned long long v0 = __builtin_amdgcn_ballot_w64(PK(P, thr4, 0) < inf);   // slot 0 fills first
-  if (v0 == 0ull) return true;                                                        // no live ray in this wave
+  B.live = v0 != 0ull;
+  B.narrow = false;
+  B.rox = B.roy = B.roz = B.ax = B.ay = B.az = B.cth = B.sth = B.rho = 0.0f;
+  if (!B.live) return B;
   const int lead = (int)__builtin_ctzll(v0);
 #define CFT_RL(x) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lead))
-  const float rox = 0.25f * CFT_RL(PK(P, o4x, 0)), roy = 0.25f * CFT_RL(PK(P, o4y, 0)), roz = 0.25f * CFT_RL(PK(P, o4z, 0));
-  const float ax = CFT_RL(PK(P, dx, 0)), ay = CFT_RL(PK(P, dy, 0)), az = CFT_RL(PK(P, dz, 0));
+  B.rox = 0.25f * CFT_RL(PK(P, o4x, 0)); B.roy = 0.25f * CFT_RL(PK(P, o4y, 0)); B.roz = 0.25f * CFT_RL(PK(P, o4z, 0));
+  B.ax = CFT_RL(PK(P, dx, 0)); B.ay = CFT_RL(PK(P, dy, 0)); B.az = CFT_RL(PK(P, dz, 0));
 #undef CFT_RL
   float d2max = 0.0f, cmin = 1.0f;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     if (PK(P, thr4, r) < inf) {
-      const float ex = fmaf(0.25f, PK(P, o4x, r), -rox), ey = fmaf(0.25f, PK(P, o4y, r), -roy), ez = fmaf(0.25f, PK(P, o4z, r), -roz);
+      const float ex = fmaf(0.25f, PK(P, o4x, r), -B.rox), ey = fmaf(0.25f, PK(P, o4y, r), -B.roy), ez = fmaf(0.25f, PK(P, o4z, r), -B.roz);
       d2max = fmaxf(d2max, fmaf(ez, ez, fmaf(ey, ey, ex * ex)));
-      cmin = fminf(cmin, fmaf(PK(P, dz, r), az, fmaf(PK(P, dy, r), ay, PK(P, dx, r) * ax)));
+      cmin = fminf(cmin, fmaf(PK(P, dz, r), B.az, fmaf(PK(P, dy, r), B.ay, PK(P, dx, r) * B.ax)));
     }
   }
 #pragma unroll
@@ -397,24 +409,33 @@ __device__ __forceinline__ bool scan_spheres_culled(const SceneDev& S, RayPack<R
     d2max = fmaxf(d2max, __shfl_xor(d2max, o));
     cmin = fminf(cmin, __shfl_xor(cmin, o));
   }
-  const float cth = cmin - 4e-6f;                      // directions are unit to a few ulp
-  if (!(cth > 0.8f)) return false;
-  const float sth = sqrtf(fmaxf(1.0f - cth * cth, 0.0f)) * 1.0001f + 1e-6f;
-  const float rho = sqrtf(d2max) * 1.0001f;
+  B.cth = cmin - 4e-6f;                      // directions are unit to a few ulp
+  B.narrow = B.cth > 0.8f;
+  B.sth = sqrtf(fmaxf(1.0f - B.cth * B.cth, 0.0f)) * 1.0001f + 1e-6f;
+  B.rho = sqrtf(d2max) * 1.0001f;
+  return B;
+}
+
+// Can a ray of the bundle reach the sphere (centre c' relative to the scene centre, radius r)?
+__device__ __forceinline__ bool bundle_reaches(const Bundle& B, float cx, float cy, float cz, float r) {
+  const float vx = cx - B.rox, vy = cy - B.roy, vz = cz - B.roz;
+  const float L2 = fmaf(vz, vz, fmaf(vy, vy, vx * vx));
+  const float va = fmaf(vz, B.az, fmaf(vy, B.ay, vx * B.ax));
+  const float slack = 1e-5f * (1.0f + sqrtf(L2));
+  const float Rp = (r + B.rho) * 1.001f + slack;
+  const float h2 = fmaf(-Rp, Rp, L2);
+  return h2 <= 0.0f || va >= B.cth * sqrtf(fmaxf(h2, 0.0f)) - B.sth * Rp - slack;
+}
+
+template <int R, int NS>
+__device__ __forceinline__ void scan_spheres_culled(const SceneDev& S, RayPack<R, NS>& P, const Bundle& B, int lo, int hi) {
   const int lane = (int)(threadIdx.x & 63u);
   for (int s0 = lo; s0 < hi; s0 += 64) {
     const int idx = s0 + lane;
     bool pass = false;
     if (idx < hi) {
       const float4 sp = S.sphF[idx];
-      const float r = 0.25f * sqrtf(S.sphR2[idx]);
-      const float vx = fmaf(-0.5f, sp.x, -rox), vy = fmaf(-0.5f, sp.y, -roy), vz = fmaf(-0.5f, sp.z, -roz);
-      const float L2 = fmaf(vz, vz, fmaf(vy, vy, vx * vx));
-      const float va = fmaf(vz, az, fmaf(vy, ay, vx * ax));
-      const float slack = 1e-5f * (1.0f + sqrtf(L2));
-      const float Rp = (r + rho) * 1.001f + slack;
-      const float h2 = fmaf(-Rp, Rp, L2);
-      pass = h2 <= 0.0f || va >= cth * sqrtf(fmaxf(h2, 0.0f)) - sth * Rp - slack;
+      pass = bundle_reaches(B, -0.5f * sp.x, -0.5f * sp.y, -0.5f * sp.z, 0.25f * sqrtf(S.sphR2[idx]));
     }
     unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
     while (m) {
@@ -425,7 +446,30 @@ __device__ __forceinline__ bool scan_spheres_culled(const SceneDev& S, RayPack<R
       scan_sphere<R, NS>(S, P, v2f{sp[0], sp[1]}, v2f{sp[2], sp[3]}, r2x16, id);
     }
   }
-  return true;
+}
+
+// One moving sphere (8 floats: centre at time 0, r^2, moving_to, object id bits) against the R rays, once per
+// scan with that scan's motion time (object.rs:42-55).
+template <int R, int NS>
+__device__ __forceinline__ void scan_msphere(const SceneDev& S, RayPack<R, NS>& P, v8f cur, int idx) {
+  const uint32_t obj = __float_as_uint(cur[7]);
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float tm = motion_time(P.word[k][r], obj);
+      float cx = fmaf(cur[4], tm, cur[0]), cy = fmaf(cur[5], tm, cur[1]), cz = fmaf(cur[6], tm, cur[2]);
+      const float dx = PK(P, dx, r), dy = PK(P, dy, r), dz = PK(P, dz, r);
+      float ocx = fmaf(0.25f, PK(P, o4x, r), -cx), ocy = fmaf(0.25f, PK(P, o4y, r), -cy), ocz = fmaf(0.25f, PK(P, o4z, r), -cz);
+      float q = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
+      float lx = fmaf(-q, dx, ocx), ly = fmaf(-q, dy, ocy), lz = fmaf(-q, dz, ocz);
+      float d = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, cur[3])));
+      if (16.0f * d >= P.negE16[r]) {
+        float tlo = sphere_lower_bound(S, q, d, P.U[r]);
+        if (tlo >= 0.0f) cand_insert(P.c[k][r], tlo, idx);
+      }
+    }
+  }
 }
 
 // f32 scan of every non-precise primitive for R rays (indices into [sphF | msph | triF | mtri]).
@@ -435,9 +479,16 @@ template <int R, int NS, bool WCULL = false>
 __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P, int part = 0, int nparts = 1) {
   const int n4_all = (S.n_sphF + 3) >> 2;
   const int lo4 = n4_all * part / nparts, hi4 = n4_all * (part + 1) / nparts;
-  bool done = false;
-  if (WCULL && S.wave_cull) done = scan_spheres_culled<R, NS>(S, P, lo4 << 2, min(hi4 << 2, S.n_sphF));
-  if (!done) {
+  Bundle B;
+  bool cull = false;
+  if (WCULL && S.wave_cull) {
+    B = wave_bundle<R, NS>(P);
+    if (!B.live) return;          // no live ray in this wave
+    cull = B.narrow;              // wider than ~37 degrees: scan the whole lists
+  }
+  if (cull) {
+    scan_spheres_culled<R, NS>(S, P, B, lo4 << 2, min(hi4 << 2, S.n_sphF));
+  } else {
     // 4 spheres per s_load_dwordx16 (+ their r^2 in one s_load_dwordx4), fetched one batch ahead; both
     // arrays are padded on the host with never-hit spheres (k4 = +1e30) to a multiple of 4 plus one batch.
     c_f16p sp = AS_CONST(c_f16p, S.sphF);
@@ -463,35 +514,40 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P,
     c_f8p sp = AS_CONST(c_f8p, S.msphF);
     const int n = S.n_msph * (part + 1) / nparts;
     const int lo = S.n_msph * part / nparts;
-    v8f cur = sp[lo];
-    for (int s = lo; s < n; ++s) {
-      v8f nxt = sp[s + 1];   // padded by one entry on the host
-      const uint32_t obj = __float_as_uint(cur[7]);
-#pragma unroll
-      for (int k = 0; k < NS; ++k) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          float tm = motion_time(P.word[k][r], obj);
-          float cx = fmaf(cur[4], tm, cur[0]), cy = fmaf(cur[5], tm, cur[1]), cz = fmaf(cur[6], tm, cur[2]);
-          const float dx = PK(P, dx, r), dy = PK(P, dy, r), dz = PK(P, dz, r);
-          float ocx = fmaf(0.25f, PK(P, o4x, r), -cx), ocy = fmaf(0.25f, PK(P, o4y, r), -cy), ocz = fmaf(0.25f, PK(P, o4z, r), -cz);
-          float q = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
-          float lx = fmaf(-q, dx, ocx), ly = fmaf(-q, dy, ocy), lz = fmaf(-q, dz, ocz);
-          float d = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, cur[3])));
-          if (16.0f * d >= P.negE16[r]) {
-            float tlo = sphere_lower_bound(S, q, d, P.U[r]);
-            if (tlo >= 0.0f) cand_insert(P.c[k][r], tlo, base + s);
-          }
+    if (cull) {
+      // bound of the swept sphere: centre c + mv/2, radius r + |mv|/2 (time in [0, 1))
+      const int lane = (int)(threadIdx.x & 63u);
+      for (int s0 = lo; s0 < n; s0 += 64) {
+        const int idx = s0 + lane;
+        bool pass = false;
+        if (idx < n) {
+          const float4 c0 = S.msphF[2 * idx], mv = S.msphF[2 * idx + 1];
+          const float hm = 0.5f * sqrtf(fmaf(mv.z, mv.z, fmaf(mv.y, mv.y, mv.x * mv.x))) * 1.0001f;
+          pass = bundle_reaches(B, fmaf(0.5f, mv.x, c0.x), fmaf(0.5f, mv.y, c0.y), fmaf(0.5f, mv.z, c0.z),
+                                sqrtf(c0.w) * 1.0001f + hm);
+        }
+        unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+        while (m) {
+          const int id = s0 + (int)__builtin_ctzll(m);
+          m &= m - 1ull;
+          scan_msphere<R, NS>(S, P, sp[id], base + id);
         }
       }
-      cur = nxt;
+    } else {
+      v8f cur = sp[lo];
+      for (int s = lo; s < n; ++s) {
+        v8f nxt = sp[s + 1];   // padded by one entry on the host
+        scan_msphere<R, NS>(S, P, cur, base + s);
+        cur = nxt;
+      }
     }
   }
   base += S.n_msph;
   {
     c_f4p tp = AS_CONST(c_f4p, S.triF);
     const int n = S.n_triF * (part + 1) / nparts;
-    for (int s = S.n_triF * part / nparts; s < n; ++s) {
+    const int lo = S.n_triF * part / nparts;
+    auto one = [&](int s) {
       v4f a = tp[3 * s], b = tp[3 * s + 1], cc = tp[3 * s + 2];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -503,6 +559,30 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P,
           for (int k = 0; k < NS; ++k) cand_insert(P.c[k][r], tlo, base + s);
         }
       }
+    };
+    if (cull) {
+      // bound of the triangle: sphere around p0 + (e1 + e2)/3 through the farthest vertex
+      const int lane = (int)(threadIdx.x & 63u);
+      for (int s0 = lo; s0 < n; s0 += 64) {
+        const int idx = s0 + lane;
+        bool pass = false;
+        if (idx < n) {
+          const float4 p0 = S.triF[3 * idx], e1 = S.triF[3 * idx + 1], e2 = S.triF[3 * idx + 2];
+          const float gx = (e1.x + e2.x) * (1.0f / 3.0f), gy = (e1.y + e2.y) * (1.0f / 3.0f), gz = (e1.z + e2.z) * (1.0f / 3.0f);
+          const float r0 = fmaf(gz, gz, fmaf(gy, gy, gx * gx));
+          const float r1 = fmaf(e1.z - gz, e1.z - gz, fmaf(e1.y - gy, e1.y - gy, (e1.x - gx) * (e1.x - gx)));
+          const float r2 = fmaf(e2.z - gz, e2.z - gz, fmaf(e2.y - gy, e2.y - gy, (e2.x - gx) * (e2.x - gx)));
+          pass = bundle_reaches(B, p0.x + gx, p0.y + gy, p0.z + gz, sqrtf(fmaxf(r0, fmaxf(r1, r2))) * 1.001f);
+        }
+        unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+        while (m) {
+          const int id = s0 + (int)__builtin_ctzll(m);
+          m &= m - 1ull;
+          one(id);
+        }
+      }
+    } else {
+      for (int s = lo; s < n; ++s) one(s);
     }
   }
   base += S.n_triF;
