@@ -438,12 +438,20 @@ __device__ __forceinline__ void scan_spheres_culled(const SceneDev& S, RayPack<R
       pass = bundle_reaches(B, -0.5f * sp.x, -0.5f * sp.y, -0.5f * sp.z, 0.25f * sqrtf(S.sphR2[idx]));
     }
     unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
-    while (m) {
-      const int id = s0 + (int)__builtin_ctzll(m);
+    if (m) {   // walk the set bits; the next sphere's scalar loads are in flight while the current one is tested
+      int id = s0 + (int)__builtin_ctzll(m);
       m &= m - 1ull;
-      const v4f sp = AS_CONST(c_f4p, S.sphF)[id];
-      const float r2x16 = AS_CONST(c_f32p, S.sphR2)[id];
-      scan_sphere<R, NS>(S, P, v2f{sp[0], sp[1]}, v2f{sp[2], sp[3]}, r2x16, id);
+      v4f sp = AS_CONST(c_f4p, S.sphF)[id];
+      float r2x16 = AS_CONST(c_f32p, S.sphR2)[id];
+      while (true) {
+        const int idn = m ? s0 + (int)__builtin_ctzll(m) : id;
+        const v4f spn = AS_CONST(c_f4p, S.sphF)[idn];
+        const float r2n = AS_CONST(c_f32p, S.sphR2)[idn];
+        scan_sphere<R, NS>(S, P, v2f{sp[0], sp[1]}, v2f{sp[2], sp[3]}, r2x16, id);
+        if (!m) break;
+        m &= m - 1ull;
+        id = idn; sp = spn; r2x16 = r2n;
+      }
     }
   }
 }
