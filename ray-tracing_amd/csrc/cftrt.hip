@@ -550,7 +550,7 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
   if (!ctx->variant && P < (1u << 20)) R = 2;
   if (two_scans && R > 2) R = 2;
   hipStream_t st = ctx->stream;
-  static const uint32_t tail_below = getenv("CFTRT_TAIL_BELOW") ? (uint32_t)atol(getenv("CFTRT_TAIL_BELOW")) : (1u << 19);   // measured optimum on S500 (2^18..2^20 within 1 %)
+  const uint32_t tail_below = 1u << 19;   // measured optimum on S500 (2^18 .. 2^20 within 1 %)
   if (!ctx->variant && P < tail_below) {
     // too few rays to fill the chip: the list is split over the 4 waves of a block (k_trace_tail), 128 rays per block
     uint64_t blocks = ((uint64_t)P + 127) / 128;

@@ -1,18 +1,23 @@
-// kernels.h — the wavefront trace loop for gfx950: generate / intersect / shade / shadow / resolve.
+// kernels.h — the wavefront trace loop for gfx950: generate / trace level (intersect + shade) / shadow / resolve.
 //
 // What each kernel replaces in the reference (cfeitong/ray-tracing):
-//   k_generate  Camera::emit_rays                      src/ray.rs:107-136
-//   k_intersect Ray::hit + Object::hit_by + Shape::hit src/ray.rs:18-28, src/object.rs:42-55,99-138,272-302
-//   k_shade     World::trace body, HitInfo::new, Material::{scatter,render}, LightSource::looked
-//                                                      src/object.rs:326-355, src/ray.rs:233-316,
-//                                                      src/material/*.rs, src/light.rs:184-190,233-242
-//   k_shadow    PhongModel::render + is_in_shadow      src/material/basic.rs:56-98, src/light.rs
-//   k_resolve   raw[h*W+w] += p                        examples/scene.rs:97
+//   k_generate     Camera::emit_rays                      src/ray.rs:107-136
+//   k_trace_level  one World::trace level for every live ray: intersect stage + shade stage + queue append
+//   k_trace_tail   the same for levels with too few rays to fill the chip (list split over a block's waves)
+//     intersect stage (isect_setup, scan_lists, isect_hit; alone: k_intersect)
+//                  Ray::hit + Object::hit_by + Shape::hit  src/ray.rs:18-28, src/object.rs:42-55,99-138,272-302
+//     shade stage (shade_one; alone: k_shade)
+//                  World::trace body, HitInfo::new, Material::{scatter,render}, LightSource::looked
+//                                                         src/object.rs:326-355, src/ray.rs:233-316,
+//                                                         src/material/*.rs, src/light.rs:184-190,233-242
+//   k_shadow       PhongModel::render + is_in_shadow      src/material/basic.rs:56-98, src/light.rs
+//   k_resolve      raw[h*W+w] += p                        examples/scene.rs:97
 //
-// Numerics.  The linear scan culls in f32 (cancellation-free discriminant, r^2 - |oc - (oc.d)d|^2)
-// and the surviving candidate is re-evaluated in f64 with the reference's own formula, operation
-// for operation, so the reported hit distance is the f64 value the reference computes for the
-// same ray.  Built with -ffp-contract=off: every FMA in this file is explicit.
+// Numerics.  The linear scan culls in f32 - per wave (a cone around the wave's ray bundle), then per ray (7 packed
+// FMAs per ray pair and sphere), then the cancellation-free discriminant r^2 - |oc - (oc.d)d|^2 with explicit
+// error bounds - and the surviving candidates are re-evaluated in f64 with the reference's own formula,
+// operation for operation, so the reported hit is the primitive and the f64 distance the reference computes
+// for the same ray.  Built with -ffp-contract=off: every FMA in this file is explicit.
 #pragma once
 #include "device_math.h"
 #include "scene_dev.h"
