@@ -385,6 +385,48 @@ def test_wave_cull_is_exact(rt, name, W, H, spp, depth):
     assert list(sa.rays_per_level[: int(sa.levels)]) == list(sb.rays_per_level[: int(sb.levels)])
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_wave_cull_random_scenes(rt, seed):
+    """Random worlds (spheres from pebbles to boulders, a negative radius, moving spheres, triangles, squares, a cube,
+    mirrors and glass so that narrow bundles survive several bounces), camera inside the cloud: the image with the
+    wave-level cull must equal the image without it bit for bit."""
+    rng = np.random.default_rng(1000 + seed)
+    A = rt
+    world = A.World.empty()
+    mats = [A.LambertianModel(0.9).with_color((0.8, 0.6, 0.4)), A.Metal(0.0, 0.95), A.Metal(0.2, 0.9).with_color((0.9, 0.9, 1.0)),
+            A.Dielectric(1.5), A.Specular(0.9), A.Transparent(0.3, 1.3)]
+    world.add_obj(A.Object(A.Sphere((0.0, 0.0, -300.0), 300.0), mats[0]))
+    for i in range(150):
+        c = tuple(rng.uniform(-8, 8, 2)) + (float(rng.uniform(0.0, 3.0)),)
+        r = float(rng.choice([0.05, 0.2, 0.5, 1.5]) * rng.uniform(0.5, 1.5))
+        if i == 7:
+            r = -r
+        o = A.Object(A.Sphere(c, r), mats[int(rng.integers(len(mats)))])
+        if i % 5 == 0:
+            o = o.moved(tuple(rng.uniform(-0.5, 0.5, 3)))
+        world.add_obj(o)
+    for i in range(40):
+        p = rng.uniform(-8, 8, 3); p[2] = abs(p[2]) * 0.4
+        world.add_obj(A.Object(A.Triangle(tuple(p), tuple(p + rng.uniform(-1.5, 1.5, 3)), tuple(p + rng.uniform(-1.5, 1.5, 3))),
+                               mats[int(rng.integers(len(mats)))]))
+    world.add_obj(A.Object(A.Square((2.0, 1.0, 1.0), (1.0, 0.0, 0.0), (0.0, 0.6, 0.8), 1.2), mats[1]))
+    world.add_obj(A.Object(A.Cube((-3.0, 2.0, 0.6), (1.0, 0.2, 0.0), (-0.2, 1.0, 0.0), 1.0), mats[3]))
+    world.add_light(A.SkyLight())
+    cam = (A.Camera.new((6.0, -5.0, 1.5), (0.0, 0.0, 0.8)).with_fov(50.0).with_aspect(2.0).with_aperture(0.05)
+           .with_focus_dist(7.0).with_sample_rate(4))
+    W, H, depth = 256, 128, 12
+    dev = rt.default_device()
+    a, sa = world.render(cam, W, H, depth, seed=seed, return_stats=True)
+    dev.set_wave_cull(False)
+    try:
+        b, sb = world.render(cam, W, H, depth, seed=seed, return_stats=True)
+    finally:
+        dev.set_wave_cull(True)
+    assert np.array_equal(a, b)
+    assert list(sa.rays_per_level[: int(sa.levels)]) == list(sb.rays_per_level[: int(sb.levels)])
+    assert int(sa.rays) > 2 * W * H * 4          # paths do bounce
+
+
 def test_full_size_properties(rt, orc):
     """BASELINE.json configs[2] at full size (1920x1080, 64 spp, depth 50): size-independent properties."""
     world, cam = rt.scenes.s500()
