@@ -307,7 +307,8 @@ int cftrt_scene_commit(cftrt_scene* s) {
   for (int i = 0; i < nt; ++i)
     if (s->tri_mat[i] >= nm) return fail(ctx, CFTRT_ERR_INVALID, "triangle mat_id beyond the material table");
 
-  std::vector<float4> sphF, msphF, triF, mtriF;
+  std::vector<float4> sphF, msphF, msphB, triF, mtriF;
+  double rb_max = 0.;   // largest swept-bound radius of a moving sphere
   std::vector<float> sphR2;
   int prec_motion = 0;
   // scene centre: bbox centre of every non-precise primitive; the f32 lists are stored relative to it
@@ -339,6 +340,19 @@ int cftrt_scene_commit(cftrt_scene* s) {
       msphF.push_back(make_float4((float)(c[0] - bc[0]), (float)(c[1] - bc[1]), (float)(c[2] - bc[2]), (float)(r * r)));
       msphF.push_back(make_float4((float)mv[0], (float)mv[1], (float)mv[2], objbits));
       msph_gid.push_back(i);
+      {
+        // swept bound in the static list's format: the centre is c0 + t mv, t in [0, 1), evaluated in f32 by the
+        // kernel from the f32 values stored above; a sphere of radius |r| + |mv|/2 (+ slack far above those
+        // roundings) around c0 + mv/2 contains it for every t
+        const float4 c0 = msphF[msphF.size() - 2], m4 = msphF[msphF.size() - 1];
+        const double bx = (double)c0.x + 0.5 * m4.x, by = (double)c0.y + 0.5 * m4.y, bz = (double)c0.z + 0.5 * m4.z;
+        const double ml = std::sqrt((double)m4.x * m4.x + (double)m4.y * m4.y + (double)m4.z * m4.z);
+        const double cl = std::sqrt((double)c0.x * c0.x + (double)c0.y * c0.y + (double)c0.z * c0.z);
+        const double rb = (std::fabs(r) + 0.5 * ml) * (1. + 1e-5) + 1e-5 * (cl + ml) + 1e-7;
+        rb_max = std::max(rb_max, rb);
+        msphB.push_back(make_float4((float)(-2. * bx), (float)(-2. * by), (float)(-2. * bz),
+                                    (float)(4. * (bx * bx + by * by + bz * bz - rb * rb))));
+      }
     } else {
       const double cx = c[0] - bc[0], cy = c[1] - bc[1], cz = c[2] - bc[2];
       sphF.push_back(make_float4((float)(-2. * cx), (float)(-2. * cy), (float)(-2. * cz),
@@ -370,6 +384,9 @@ int cftrt_scene_commit(cftrt_scene* s) {
   }
   msphF.push_back(make_float4(0.f, 0.f, 0.f, -1e30f));   // the prefetched extra entry of the moving list
   msphF.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
+  while (msphB.size() % 4) msphB.push_back(make_float4(0.f, 0.f, 0.f, 1e30f));
+  for (int k = 0; k < 4; ++k) msphB.push_back(make_float4(0.f, 0.f, 0.f, 1e30f));
+  while (msphF.size() < 2 * msphB.size()) msphF.push_back(make_float4(0.f, 0.f, 0.f, 0.f));   // entries the pad bounds point at
   const int n_sphF_real = (int)sphF_gid.size();
   while (sphF.size() % 4) { sphF.push_back(make_float4(0.f, 0.f, 0.f, 1e30f)); sphR2.push_back(0.f); }   // never hit: 4 disc' = Q^2 - 1e30
   for (int k = 0; k < 4; ++k) { sphF.push_back(make_float4(0.f, 0.f, 0.f, 1e30f)); sphR2.push_back(0.f); }   // the prefetched extra batch
@@ -394,6 +411,7 @@ int cftrt_scene_commit(cftrt_scene* s) {
   if ((rc = upload(s, sphF_gid, &D.sphF_gid))) return rc;
   if ((rc = upload(s, sphR2, &D.sphR2))) return rc;
   if ((rc = upload(s, msphF, &D.msphF))) return rc;
+  if ((rc = upload(s, msphB, &D.msphB))) return rc;
   if ((rc = upload(s, msph_gid, &D.msph_gid))) return rc;
   if ((rc = upload(s, prec_gid, &D.prec_gid))) return rc;
   if ((rc = upload(s, triF, &D.triF))) return rc;
@@ -441,7 +459,7 @@ int cftrt_scene_commit(cftrt_scene* s) {
     D.K3 = (float)(12. * eps);
     D.K4 = (float)(eps * (24. * rmax + 6. * cmax));
     D.Kc = (float)(36. * eps);
-    D.rmax2 = (float)(rmax * rmax);
+    D.rmax2 = (float)(std::max(rmax, rb_max) * std::max(rmax, rb_max));   // the cull also runs on the moving spheres' swept bounds
     D.bcx = bcf[0]; D.bcy = bcf[1]; D.bcz = bcf[2];
     D.brad = (float)(brad * 1.000001 + 1e-6);
     double emax = 0., pmax = 0.;
@@ -550,30 +568,41 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
   if (!ctx->variant && P < (1u << 20)) R = 2;
   if (two_scans && R > 2) R = 2;
   hipStream_t st = ctx->stream;
+  // static spheres only (S500 and the like): kernels compiled without the moving-sphere and triangle lists
+  const bool lean = !S.n_msph && !S.n_triF && !S.n_mtri;
   const uint32_t tail_below = 1u << 19;   // measured optimum on S500 (2^18 .. 2^20 within 1 %)
   if (!ctx->variant && P < tail_below) {
     // too few rays to fill the chip: the list is split over the 4 waves of a block (k_trace_tail), 128 rays per block
     uint64_t blocks = ((uint64_t)P + 127) / 128;
     blocks = std::max<uint64_t>(1, std::min<uint64_t>(blocks, (uint64_t)ctx->n_cu * 8));
-    if (two_scans)
-      hipLaunchKernelGGL((k_trace_tail<2, 2>), dim3((uint32_t)blocks), dim3(CFT_BLOCK), 0, st, S, q, counts, level, max_depth,
-                         pid_base, k0, k1, role0, role1, qout, rad, pq, phong_counts, xstats);
-    else
-      hipLaunchKernelGGL((k_trace_tail<2, 1>), dim3((uint32_t)blocks), dim3(CFT_BLOCK), 0, st, S, q, counts, level, max_depth,
-                         pid_base, k0, k1, role0, role1, qout, rad, pq, phong_counts, xstats);
+#define CFT_TAIL(NN, LL) hipLaunchKernelGGL((k_trace_tail<2, NN, LL>), dim3((uint32_t)blocks), dim3(CFT_BLOCK), 0, st, S, q, \
+                                            counts, level, max_depth, pid_base, k0, k1, role0, role1, qout, rad, pq,       \
+                                            phong_counts, xstats)
+    if (two_scans) CFT_TAIL(2, 3);
+    else if (lean) CFT_TAIL(1, 0);
+    else CFT_TAIL(1, 3);
+#undef CFT_TAIL
     return;
   }
   const uint32_t g = grid_for(ctx, ((uint64_t)P + R - 1) / R, 8);
-#define CFT_LAUNCH(RR, NN) hipLaunchKernelGGL((k_trace_level<RR, NN>), dim3(g), dim3(CFT_BLOCK), 0, st, S, q, counts, level, \
-                                              max_depth, pid_base, k0, k1, role0, role1, qout, rad, pq, phong_counts, xstats)
+#define CFT_LAUNCH(RR, NN, LL) hipLaunchKernelGGL((k_trace_level<RR, NN, LL>), dim3(g), dim3(CFT_BLOCK), 0, st, S, q, counts, \
+                                                  level, max_depth, pid_base, k0, k1, role0, role1, qout, rad, pq,            \
+                                                  phong_counts, xstats)
   if (two_scans) {
-    if (R == 1) CFT_LAUNCH(1, 2); else CFT_LAUNCH(2, 2);
+    if (R == 1) CFT_LAUNCH(1, 2, 3); else CFT_LAUNCH(2, 2, 3);
+  } else if (lean) {
+    switch (R) {
+      case 1: CFT_LAUNCH(1, 1, 0); break;
+      case 3: CFT_LAUNCH(3, 1, 0); break;
+      case 4: CFT_LAUNCH(4, 1, 0); break;
+      default: CFT_LAUNCH(2, 1, 0); break;
+    }
   } else {
     switch (R) {
-      case 1: CFT_LAUNCH(1, 1); break;
-      case 3: CFT_LAUNCH(3, 1); break;
-      case 4: CFT_LAUNCH(4, 1); break;
-      default: CFT_LAUNCH(2, 1); break;
+      case 1: CFT_LAUNCH(1, 1, 3); break;
+      case 3: CFT_LAUNCH(3, 1, 3); break;
+      case 4: CFT_LAUNCH(4, 1, 3); break;
+      default: CFT_LAUNCH(2, 1, 3); break;
     }
   }
 #undef CFT_LAUNCH

@@ -461,34 +461,58 @@ __device__ __forceinline__ void scan_spheres_culled(const SceneDev& S, RayPack<R
   }
 }
 
-// One moving sphere (8 floats: centre at time 0, r^2, moving_to, object id bits) against the R rays, once per
-// scan with that scan's motion time (object.rs:42-55).
+// A moving sphere whose swept bound the cull could not rule out for ray slot r (entry: 8 floats - centre at
+// time 0, r^2, moving_to, object id bits): per scan, the centre at that scan's motion time (object.rs:42-55),
+// the cancellation-free discriminant, the lower bound, the insert.
 template <int R, int NS>
-__device__ __forceinline__ void scan_msphere(const SceneDev& S, RayPack<R, NS>& P, v8f cur, int idx) {
+__device__ __forceinline__ void msphere_candidate(const SceneDev& S, RayPack<R, NS>& P, int r, v8f cur, int idx) {
   const uint32_t obj = __float_as_uint(cur[7]);
+  const float dx = PK(P, dx, r), dy = PK(P, dy, r), dz = PK(P, dz, r);
+  const float tx = 0.25f * PK(P, o4x, r), ty = 0.25f * PK(P, o4y, r), tz = 0.25f * PK(P, o4z, r);
 #pragma unroll
   for (int k = 0; k < NS; ++k) {
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      float tm = motion_time(P.word[k][r], obj);
-      float cx = fmaf(cur[4], tm, cur[0]), cy = fmaf(cur[5], tm, cur[1]), cz = fmaf(cur[6], tm, cur[2]);
-      const float dx = PK(P, dx, r), dy = PK(P, dy, r), dz = PK(P, dz, r);
-      float ocx = fmaf(0.25f, PK(P, o4x, r), -cx), ocy = fmaf(0.25f, PK(P, o4y, r), -cy), ocz = fmaf(0.25f, PK(P, o4z, r), -cz);
-      float q = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
-      float lx = fmaf(-q, dx, ocx), ly = fmaf(-q, dy, ocy), lz = fmaf(-q, dz, ocz);
-      float d = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, cur[3])));
-      if (16.0f * d >= P.negE16[r]) {
-        float tlo = sphere_lower_bound(S, q, d, P.U[r]);
-        if (tlo >= 0.0f) cand_insert(P.c[k][r], tlo, idx);
-      }
+    float tm = motion_time(P.word[k][r], obj);
+    float cx = fmaf(cur[4], tm, cur[0]), cy = fmaf(cur[5], tm, cur[1]), cz = fmaf(cur[6], tm, cur[2]);
+    float ocx = tx - cx, ocy = ty - cy, ocz = tz - cz;
+    float q = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
+    float lx = fmaf(-q, dx, ocx), ly = fmaf(-q, dy, ocy), lz = fmaf(-q, dz, ocz);
+    float d = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, cur[3])));
+    if (16.0f * d >= P.negE16[r]) {
+      float tlo = sphere_lower_bound(S, q, d, P.U[r]);
+      if (tlo >= 0.0f) cand_insert(P.c[k][r], tlo, idx);
     }
+  }
+}
+
+// One moving sphere against R rays: the per-ray cull runs on the sphere's swept bound (an entry of S.msphB in the
+// static list's format, so the 7 packed FMAs and the one compare serve it too); lanes that pass fetch the
+// sphere itself and test it at their own motion times.  s = index in the moving list.
+template <int R, int NS>
+__device__ __forceinline__ void scan_msphere(const SceneDev& S, RayPack<R, NS>& P, v2f cxy, v2f czk, int s) {
+  constexpr int NP = RayPack<R, NS>::NP;
+  v2f V[NP];
+#pragma unroll
+  for (int h = 0; h < NP; ++h)
+    V[h] = pair_cull(cxy, czk, P.dx[h], P.dy[h], P.dz[h], P.od2[h], P.o4x[h], P.o4y[h], P.o4z[h], P.thr4[h]);
+  float m;
+  asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(V[0].x), "v"(V[0].y));
+#pragma unroll
+  for (int h = 1; h < NP; ++h) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(m), "v"(V[h].x), "v"(V[h].y));
+  const float k4 = czk.y;
+  if (__builtin_amdgcn_ballot_w64(m >= k4) != 0ull) {
+    const v8f cur = AS_CONST(c_f8p, S.msphF)[s];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (V[r >> 1][r & 1] >= k4) msphere_candidate<R, NS>(S, P, r, cur, S.n_sphF + s);
   }
 }
 
 // f32 scan of every non-precise primitive for R rays (indices into [sphF | msph | triF | mtri]).
 // part / nparts (wave-uniform): this wave scans the part-th slice of each list (nparts = 1: all of it).
 // WCULL: try the wave-level cull first (the R-rays-per-lane kernels; every lane of the wave must be active).
-template <int R, int NS, bool WCULL = false>
+// LISTS (compile time): 1 = the scene may hold moving spheres, 2 = triangles; a scene of static spheres only runs
+// kernels without that code (and its registers).
+template <int R, int NS, bool WCULL = false, int LISTS = 3>
 __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P, int part = 0, int nparts = 1) {
   const int n4_all = (S.n_sphF + 3) >> 2;
   const int lo4 = n4_all * part / nparts, hi4 = n4_all * (part + 1) / nparts;
@@ -521,15 +545,14 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P,
     }
   }
   int base = S.n_sphF;
-  if (S.n_msph) {
-    // moving spheres, 8 floats each: (cx, cy, cz, r^2, mvx, mvy, mvz, object id); centre + time * moving_to
-    // with one fresh time per object per scan (object.rs:42-55)
-    c_f8p sp = AS_CONST(c_f8p, S.msphF);
-    const int n = S.n_msph * (part + 1) / nparts;
-    const int lo = S.n_msph * part / nparts;
+  if ((LISTS & 1) && S.n_msph) {
+    // moving spheres: the cull runs on their swept bounds (S.msphB, same format and padding as sphF)
+    const int m4_all = (S.n_msph + 3) >> 2;
+    const int mlo4 = m4_all * part / nparts, mhi4 = m4_all * (part + 1) / nparts;
     if (cull) {
-      // bound of the swept sphere: centre c + mv/2, radius r + |mv|/2 (time in [0, 1))
+      // the swept bound against the wave's cone, one lane per sphere; bound centre = -C/2, radius from k4
       const int lane = (int)(threadIdx.x & 63u);
+      const int lo = mlo4 << 2, n = min(mhi4 << 2, S.n_msph);
       for (int s0 = lo; s0 < n; s0 += 64) {
         const int idx = s0 + lane;
         bool pass = false;
@@ -543,20 +566,26 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P,
         while (m) {
           const int id = s0 + (int)__builtin_ctzll(m);
           m &= m - 1ull;
-          scan_msphere<R, NS>(S, P, sp[id], base + id);
+          const v4f sb = AS_CONST(c_f4p, S.msphB)[id];
+          scan_msphere<R, NS>(S, P, v2f{sb[0], sb[1]}, v2f{sb[2], sb[3]}, id);
         }
       }
     } else {
-      v8f cur = sp[lo];
-      for (int s = lo; s < n; ++s) {
-        v8f nxt = sp[s + 1];   // padded by one entry on the host
-        scan_msphere<R, NS>(S, P, cur, base + s);
+      c_f16p sp = AS_CONST(c_f16p, S.msphB);
+      v16f cur = sp[mlo4];
+      for (int s4 = mlo4; s4 < mhi4; ++s4) {
+        v16f nxt = sp[s4 + 1];
+        const int s = s4 << 2;
+        scan_msphere<R, NS>(S, P, v2f{cur[0], cur[1]}, v2f{cur[2], cur[3]}, s);
+        scan_msphere<R, NS>(S, P, v2f{cur[4], cur[5]}, v2f{cur[6], cur[7]}, s + 1);
+        scan_msphere<R, NS>(S, P, v2f{cur[8], cur[9]}, v2f{cur[10], cur[11]}, s + 2);
+        scan_msphere<R, NS>(S, P, v2f{cur[12], cur[13]}, v2f{cur[14], cur[15]}, s + 3);
         cur = nxt;
       }
     }
   }
   base += S.n_msph;
-  {
+  if (LISTS & 2) {
     c_f4p tp = AS_CONST(c_f4p, S.triF);
     const int n = S.n_triF * (part + 1) / nparts;
     const int lo = S.n_triF * part / nparts;
@@ -599,7 +628,7 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P,
     }
   }
   base += S.n_triF;
-  if (S.n_mtri) {   // moving triangles, 4 float4 each: p0, e1, e2, (mv, object id)
+  if ((LISTS & 2) && S.n_mtri) {   // moving triangles, 4 float4 each: p0, e1, e2, (mv, object id)
     c_f4p tp = AS_CONST(c_f4p, S.mtriF);
     for (int s = S.n_mtri * part / nparts; s < S.n_mtri * (part + 1) / nparts; ++s) {
       v4f a = tp[4 * s], b = tp[4 * s + 1], cc = tp[4 * s + 2], m = tp[4 * s + 3];
@@ -1210,7 +1239,7 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_shade(SceneDev S, QueueDev qin, H
 // ballot + prefix popcount order them inside the wave and ONE global atomic per wave and loop trip (R x 64 rays)
 // reserves their slots - 4x fewer atomics than one per wave and ray row, below the ~88/us a single counter
 // sustains.
-template <int R, int NS>
+template <int R, int NS, int LISTS>
 __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(SceneDev S, QueueDev q, uint32_t* counts, uint32_t level,
                                                            uint32_t max_depth, uint64_t pid_base, uint32_t k0,
                                                            uint32_t k1, uint32_t role0, uint32_t role1, QueueDev qout,
@@ -1226,7 +1255,7 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(SceneDev S, QueueD
     {
       RayPack<R, NS> P;
       isect_setup<R, NS>(S, q, n, base, stride, level, pid_base, k0, k1, role0, role1, P, park);
-      scan_lists<R, NS, true>(S, P);
+      scan_lists<R, NS, true, LISTS>(S, P);
       isect_park<R, NS>(P, park);
     }
     uint32_t alive_bits = 0;
@@ -1280,7 +1309,7 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(SceneDev S, QueueD
 // over the four waves of a block: all four take the same 64 x R rays, each scans a quarter of every list, the
 // candidate sets meet in the LDS park (a wave's top three bounds, merged best-two-first so that a third bound
 // never displaces an indexed one on a tie), and wave 0 finishes, shades and appends as usual.
-template <int R, int NS>
+template <int R, int NS, int LISTS>
 __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_tail(SceneDev S, QueueDev q, uint32_t* counts, uint32_t level,
                                                           uint32_t max_depth, uint64_t pid_base, uint32_t k0,
                                                           uint32_t k1, uint32_t role0, uint32_t role1, QueueDev qout,
@@ -1296,7 +1325,7 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_tail(SceneDev S, QueueDe
     {
       RayPack<R, NS> P;
       isect_setup<R, NS>(S, q, n, base, stride, level, pid_base, k0, k1, role0, role1, P, park);
-      scan_lists<R, NS, true>(S, P, wave, CFT_BLOCK / 64);
+      scan_lists<R, NS, true, LISTS>(S, P, wave, CFT_BLOCK / 64);
       isect_park<R, NS>(P, park);
     }
     __syncthreads();

@@ -30,6 +30,7 @@ struct SceneDev {
   const int* sphF_gid;    // -> global prim id
   int n_sphF;
   const float4* msphF;    // moving spheres, 2 float4 each: (cx, cy, cz, r^2) at time 0, (mvx, mvy, mvz, object id bits)
+  const float4* msphB;    // their swept bounds in sphF's format (-2 b', 4 (|b'|^2 - rb^2)), padded like sphF
   const int* msph_gid;
   int n_msph;
   const int* prec_gid;    // "precise" spheres (|r| >= precise_radius): exact f64 test for every ray
