@@ -98,6 +98,9 @@ def main():
     dev.set_pipeline(split)
     if os.environ.get("CFTRT_WAVE_CULL"):
         dev.set_wave_cull(int(os.environ["CFTRT_WAVE_CULL"]))   # 0: plain linear scan, for profiling
+    if os.environ.get("CFTRT_GRID"):
+        g = os.environ["CFTRT_GRID"].split(",")                # "mode[,cells_per_prim]"; 0: the plain lists, for profiling
+        dev.set_grid(int(g[0]), float(g[1]) if len(g) > 1 else 0.0)
     scene.commit(dev)
     accum = torch.zeros(H * W * 3, dtype=torch.float32, device=f"cuda:{local_rank}")
     spp_begin, spp_end = rank * spp, (rank + 1) * spp

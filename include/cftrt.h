@@ -125,6 +125,15 @@ int cftrt_ctx_set_pipeline(cftrt_ctx* ctx, int split);
  * reach (a conservative cone test per sphere and wave) before the per-ray cull.  Results are identical with it
  * off; the switch exists for that comparison (tests) and for profiling the plain linear scan. */
 int cftrt_ctx_set_wave_cull(cftrt_ctx* ctx, int on);
+/* Uniform grid - an EXTENSION: it has no counterpart in the reference, whose Ray::hit scans every object (src/ray.rs:18-28).
+ * cftrt_scene_commit also registers the static spheres, the swept bounds of moving spheres and the static
+ * triangles of a scene with >= 64 of them in a uniform grid; rays then test only the primitives of the cells they
+ * cross and stop behind the nearest candidate.  The candidates go through the same exact f64 evaluation as those
+ * of the list scan, so images are identical bit for bit with any mode.
+ *   mode 0: lists only (the reference's linear scan);  1 (default): waves whose ray bundle is too wide for the
+ *   wave-level cull walk the grid;  2: every wave does.
+ *   cells_per_prim > 0 sets the grid resolution for scenes committed afterwards (default 4); <= 0 keeps it. */
+int cftrt_ctx_set_grid(cftrt_ctx* ctx, int mode, double cells_per_prim);
 /* Intersect-kernel variant: rays per lane of k_intersect / k_trace_level (1..4); 0 = the tuned default. */
 int cftrt_ctx_set_variant(cftrt_ctx* ctx, int variant);
 

@@ -54,6 +54,7 @@ SYMBOLS = [
     ("cftrt_ctx_set_workspace_limit", C.c_int, [_P, C.c_uint64]),
     ("cftrt_ctx_set_pipeline", C.c_int, [_P, C.c_int]),
     ("cftrt_ctx_set_wave_cull", C.c_int, [_P, C.c_int]),
+    ("cftrt_ctx_set_grid", C.c_int, [_P, C.c_int, C.c_double]),
     ("cftrt_ctx_set_variant", C.c_int, [_P, C.c_int]),
     ("cftrt_scene_create", C.c_int, [_P, C.POINTER(_P)]),
     ("cftrt_scene_destroy", None, [_P]),

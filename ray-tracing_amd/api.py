@@ -357,6 +357,12 @@ class Device:
         """Wave-level sphere cull of the level kernels (default on); images are identical either way."""
         self.check(self.lib.cftrt_ctx_set_wave_cull(self.h, int(bool(on))))
 
+    def set_grid(self, mode, cells_per_prim=0.0):
+        """Uniform grid (an extension to the reference's linear scan): 0 lists only, 1 (default) waves the cone
+        cull does not serve, 2 every wave; cells_per_prim > 0 sizes the grid of scenes committed afterwards.
+        Images are identical with any mode."""
+        self.check(self.lib.cftrt_ctx_set_grid(self.h, int(mode), float(cells_per_prim)))
+
     def set_variant(self, v):
         self.check(self.lib.cftrt_ctx_set_variant(self.h, int(v)))
 

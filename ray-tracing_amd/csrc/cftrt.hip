@@ -24,6 +24,8 @@ struct cftrt_ctx {
   uint64_t ws_limit = 40ull << 30;
   int variant = 0;
   int wave_cull = 1;      // level kernels may skip spheres no ray of a wave's bundle can reach (exact either way)
+  int grid = 1;           // uniform grid (an extension to the reference's linear scan): 0 off, 1 waves the cone cull does not serve, 2 every wave
+  double grid_density = 4.;   // cells per primitive the grid is sized for (scenes committed afterwards)
   int split = 0;          // 0: fused k_trace_level per level (default); 1: k_intersect -> hit records -> k_shade
   int n_cu = 256;
   // grow-only workspace
@@ -168,6 +170,14 @@ int cftrt_ctx_set_wave_cull(cftrt_ctx* ctx, int on) {
   return CFTRT_OK;
 }
 
+int cftrt_ctx_set_grid(cftrt_ctx* ctx, int mode, double cells_per_prim) {
+  if (!ctx) return CFTRT_ERR_INVALID;
+  if (mode < 0 || mode > 2) return fail(ctx, CFTRT_ERR_INVALID, "grid mode must be 0, 1 or 2");
+  ctx->grid = mode;
+  if (cells_per_prim > 0.) ctx->grid_density = cells_per_prim;
+  return CFTRT_OK;
+}
+
 int cftrt_ctx_set_pipeline(cftrt_ctx* ctx, int split) {
   if (!ctx) return CFTRT_ERR_INVALID;
   if (split != 0 && split != 1) return fail(ctx, CFTRT_ERR_INVALID, "pipeline must be 0 (fused) or 1 (split)");
@@ -309,6 +319,7 @@ int cftrt_scene_commit(cftrt_scene* s) {
 
   std::vector<float4> sphF, msphF, msphB, triF, mtriF;
   double rb_max = 0.;   // largest swept-bound radius of a moving sphere
+  std::vector<double> msph_rb;   // swept-bound radii (for the grid)
   std::vector<float> sphR2;
   int prec_motion = 0;
   // scene centre: bbox centre of every non-precise primitive; the f32 lists are stored relative to it
@@ -350,6 +361,7 @@ int cftrt_scene_commit(cftrt_scene* s) {
         const double cl = std::sqrt((double)c0.x * c0.x + (double)c0.y * c0.y + (double)c0.z * c0.z);
         const double rb = (std::fabs(r) + 0.5 * ml) * (1. + 1e-5) + 1e-5 * (cl + ml) + 1e-7;
         rb_max = std::max(rb_max, rb);
+        msph_rb.push_back(rb);
         msphB.push_back(make_float4((float)(-2. * bx), (float)(-2. * by), (float)(-2. * bz),
                                     (float)(4. * (bx * bx + by * by + bz * bz - rb * rb))));
       }
@@ -390,6 +402,106 @@ int cftrt_scene_commit(cftrt_scene* s) {
   const int n_sphF_real = (int)sphF_gid.size();
   while (sphF.size() % 4) { sphF.push_back(make_float4(0.f, 0.f, 0.f, 1e30f)); sphR2.push_back(0.f); }   // never hit: 4 disc' = Q^2 - 1e30
   for (int k = 0; k < 4; ++k) { sphF.push_back(make_float4(0.f, 0.f, 0.f, 1e30f)); sphR2.push_back(0.f); }   // the prefetched extra batch
+  // Uniform grid over the static spheres, the moving spheres' swept bounds and the static triangles (kernels.h,
+  // grid_walk_ray).  Cubic cells sized for ~4 cells per primitive, at most 128 per axis; every primitive is
+  // registered in the cells its bound, inflated by 1e-3 of the box half-extent, overlaps.  Scenes with fewer than 64
+  // such primitives, or whose primitives are large against any sensible cell (a Cornell box), get no grid.
+  std::vector<uint4> gridCell;
+  std::vector<float4> gridSph;
+  std::vector<uint32_t> gridTri;
+  struct { int n[3]; double lo[3], hi[3], cs[3], far; } G = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, 0};
+  {
+    const int nS = n_sphF_real, nM = (int)msph_gid.size(), nT = (int)triF_gid.size(), nP = nS + nM + nT;
+    struct Box { double lo[3], hi[3]; };
+    std::vector<Box> bx((size_t)nP);
+    std::vector<double> cen(3 * (size_t)(nS + nM)), rad((size_t)(nS + nM));
+    for (int i = 0; i < nS + nM; ++i) {
+      const float4 e = i < nS ? sphF[i] : msphB[i - nS];
+      const double c[3] = {-0.5 * e.x, -0.5 * e.y, -0.5 * e.z};
+      const double r = i < nS ? 0.25 * std::sqrt((double)sphR2[i]) : msph_rb[i - nS];
+      for (int k = 0; k < 3; ++k) { cen[3 * i + k] = c[k]; bx[i].lo[k] = c[k] - r; bx[i].hi[k] = c[k] + r; }
+      rad[i] = r;
+    }
+    for (int i = 0; i < nT; ++i) {
+      const float4 p0 = triF[3 * i], e1 = triF[3 * i + 1], e2 = triF[3 * i + 2];
+      const double v[3][3] = {{p0.x, p0.y, p0.z}, {(double)p0.x + e1.x, (double)p0.y + e1.y, (double)p0.z + e1.z},
+                              {(double)p0.x + e2.x, (double)p0.y + e2.y, (double)p0.z + e2.z}};
+      Box& b = bx[nS + nM + i];
+      for (int k = 0; k < 3; ++k) {
+        b.lo[k] = std::min(v[0][k], std::min(v[1][k], v[2][k]));
+        b.hi[k] = std::max(v[0][k], std::max(v[1][k], v[2][k]));
+      }
+    }
+    if (nP >= 64) {
+      double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
+      for (const Box& b : bx) for (int k = 0; k < 3; ++k) { blo[k] = std::min(blo[k], b.lo[k]); bhi[k] = std::max(bhi[k], b.hi[k]); }
+      double E = 0.;
+      for (int k = 0; k < 3; ++k) E = std::max(E, std::max(std::fabs(blo[k]), std::fabs(bhi[k])));
+      const double margin = 1e-3 * E;
+      double ext[3], vol = 1.;
+      for (int k = 0; k < 3; ++k) { blo[k] -= 2. * margin; bhi[k] += 2. * margin; ext[k] = bhi[k] - blo[k]; vol *= ext[k]; }
+      double cell = std::cbrt(vol / (ctx->grid_density * nP));
+      for (int attempt = 0; attempt < 4 && !G.n[0]; ++attempt, cell *= 2.) {
+        int n[3];
+        double cs[3];
+        for (int k = 0; k < 3; ++k) {
+          n[k] = (int)std::min(128., std::max(1., std::ceil(ext[k] / cell)));
+          cs[k] = ext[k] / n[k];
+        }
+        const size_t nc = (size_t)n[0] * n[1] * n[2];
+        std::vector<uint32_t> cntS(nc, 0), cntT(nc, 0);
+        size_t total = 0;
+        // two passes over the same enumeration: count, then fill
+        auto each_cell = [&](int i, auto&& f) {
+          int a[3], b[3];
+          for (int k = 0; k < 3; ++k) {
+            a[k] = std::min(n[k] - 1, std::max(0, (int)std::floor((bx[i].lo[k] - margin - blo[k]) / cs[k])));
+            b[k] = std::min(n[k] - 1, std::max(0, (int)std::floor((bx[i].hi[k] + margin - blo[k]) / cs[k])));
+          }
+          for (int z = a[2]; z <= b[2]; ++z)
+            for (int y = a[1]; y <= b[1]; ++y)
+              for (int x = a[0]; x <= b[0]; ++x) {
+                if (i < nS + nM) {   // sphere against the cell box, not just its own box against it
+                  const int c3[3] = {x, y, z};
+                  double d2 = 0.;
+                  for (int k = 0; k < 3; ++k) {
+                    const double lo_k = blo[k] + c3[k] * cs[k], hi_k = lo_k + cs[k], c = cen[3 * i + k];
+                    const double d = c < lo_k ? lo_k - c : (c > hi_k ? c - hi_k : 0.);
+                    d2 += d * d;
+                  }
+                  const double rr = rad[i] + margin;
+                  if (d2 > rr * rr) continue;
+                }
+                f(((size_t)z * n[1] + y) * n[0] + x);
+              }
+        };
+        for (int i = 0; i < nP; ++i) each_cell(i, [&](size_t c) { (i < nS + nM ? cntS : cntT)[c]++; total++; });
+        if (total > 24 * (size_t)nP) continue;   // primitives much larger than the cells: coarser
+        gridCell.resize(nc);
+        uint32_t oS = 0, oT = 0;
+        for (size_t c = 0; c < nc; ++c) { gridCell[c] = make_uint4(oS, 0, oT, 0); oS += cntS[c]; oT += cntT[c]; }
+        gridSph.resize(2 * (size_t)oS);
+        gridTri.resize(oT);
+        for (int i = 0; i < nP; ++i)
+          each_cell(i, [&](size_t c) {
+            if (i < nS + nM) {
+              const size_t e = (size_t)gridCell[c].x + gridCell[c].y++;
+              float ib;
+              memcpy(&ib, &i, 4);
+              gridSph[2 * e] = i < nS ? sphF[i] : msphB[i - nS];
+              gridSph[2 * e + 1] = make_float4(i < nS ? sphR2[i] : 0.f, ib, 0.f, 0.f);
+            } else {
+              gridTri[(size_t)gridCell[c].z + gridCell[c].w++] = (uint32_t)(i - nS - nM);
+            }
+          });
+        for (int k = 0; k < 3; ++k) { G.n[k] = n[k]; G.lo[k] = blo[k]; G.hi[k] = bhi[k]; G.cs[k] = cs[k]; }
+        G.far = 4. * E;
+      }
+    }
+    if (gridSph.empty()) gridSph.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
+    if (gridTri.empty()) gridTri.push_back(0u);
+    if (gridCell.empty()) gridCell.push_back(make_uint4(0, 0, 0, 0));
+  }
   std::vector<MatDev> mats(nm);
   int n_phong = 0;
   for (int i = 0; i < nm; ++i) {
@@ -418,6 +530,9 @@ int cftrt_scene_commit(cftrt_scene* s) {
   if ((rc = upload(s, triF_gid, &D.triF_gid))) return rc;
   if ((rc = upload(s, mtriF, &D.mtriF))) return rc;
   if ((rc = upload(s, mtri_gid, &D.mtri_gid))) return rc;
+  if ((rc = upload(s, gridCell, &D.gridCell))) return rc;
+  if ((rc = upload(s, gridSph, &D.gridSph))) return rc;
+  if ((rc = upload(s, gridTri, &D.gridTri))) return rc;
   if ((rc = upload(s, sphD, &D.sphD))) return rc;
   if ((rc = upload(s, s->sph_mv, &D.sphMvD))) return rc;
   if ((rc = upload(s, s->tri_p, &D.triD))) return rc;
@@ -440,6 +555,16 @@ int cftrt_scene_commit(cftrt_scene* s) {
   D.any_motion = any_motion;
   D.prec_motion = prec_motion;
   D.n_phong_mats = n_phong;
+  D.gnx = G.n[0]; D.gny = G.n[1]; D.gnz = G.n[2];
+  D.grid_mode = 0;   // set per pass from the ctx (cftrt_ctx_set_grid)
+  if (G.n[0]) {
+    // the box as the kernel sees it: low corner rounded down, high corner up (the box only grows)
+    D.g0x = std::nextafterf((float)G.lo[0], -INFINITY); D.g0y = std::nextafterf((float)G.lo[1], -INFINITY); D.g0z = std::nextafterf((float)G.lo[2], -INFINITY);
+    D.g1x = std::nextafterf((float)G.hi[0], INFINITY); D.g1y = std::nextafterf((float)G.hi[1], INFINITY); D.g1z = std::nextafterf((float)G.hi[2], INFINITY);
+    D.gcsx = (float)G.cs[0]; D.gcsy = (float)G.cs[1]; D.gcsz = (float)G.cs[2];
+    D.gicx = (float)(1. / G.cs[0]); D.gicy = (float)(1. / G.cs[1]); D.gicz = (float)(1. / G.cs[2]);
+    D.gfar4 = (float)(4. * G.far);
+  }
   {
     // f32 error model of the cull.  eps = 2^-24 (unit roundoff); every constant carries
     // a factor >= 2 over the bound derived there.
@@ -571,7 +696,8 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
   // static spheres only (S500 and the like): kernels compiled without the moving-sphere and triangle lists
   const bool lean = !S.n_msph && !S.n_triF && !S.n_mtri;
   const uint32_t tail_below = 1u << 19;   // measured optimum on S500 (2^18 .. 2^20 within 1 %)
-  if (!ctx->variant && P < tail_below) {
+  // (with the grid no wave scans a whole list; short lists are still quicker split over the four waves)
+  if (!ctx->variant && P < tail_below && (!S.grid_mode || S.n_sphF + S.n_msph + S.n_triF <= 2048)) {
     // too few rays to fill the chip: the list is split over the 4 waves of a block (k_trace_tail), 128 rays per block
     uint64_t blocks = ((uint64_t)P + 127) / 128;
     blocks = std::max<uint64_t>(1, std::min<uint64_t>(blocks, (uint64_t)ctx->n_cu * 8));
@@ -588,23 +714,21 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
 #define CFT_LAUNCH(RR, NN, LL) hipLaunchKernelGGL((k_trace_level<RR, NN, LL>), dim3(g), dim3(CFT_BLOCK), 0, st, S, q, counts, \
                                                   level, max_depth, pid_base, k0, k1, role0, role1, qout, rad, pq,            \
                                                   phong_counts, xstats)
-  if (two_scans) {
-    if (R == 1) CFT_LAUNCH(1, 2, 3); else CFT_LAUNCH(2, 2, 3);
-  } else if (lean) {
-    switch (R) {
-      case 1: CFT_LAUNCH(1, 1, 0); break;
-      case 3: CFT_LAUNCH(3, 1, 0); break;
-      case 4: CFT_LAUNCH(4, 1, 0); break;
-      default: CFT_LAUNCH(2, 1, 0); break;
-    }
-  } else {
-    switch (R) {
-      case 1: CFT_LAUNCH(1, 1, 3); break;
-      case 3: CFT_LAUNCH(3, 1, 3); break;
-      case 4: CFT_LAUNCH(4, 1, 3); break;
-      default: CFT_LAUNCH(2, 1, 3); break;
-    }
+#define CFT_LAUNCH_R(LL)                                                    \
+  if (two_scans) {                                                        \
+    if (R == 1) CFT_LAUNCH(1, 2, (LL) | 3); else CFT_LAUNCH(2, 2, (LL) | 3);  \
+  } else {                                                                \
+    switch (R) {                                                          \
+      case 1: CFT_LAUNCH(1, 1, LL); break;                                \
+      case 3: CFT_LAUNCH(3, 1, LL); break;                                \
+      case 4: CFT_LAUNCH(4, 1, LL); break;                                \
+      default: CFT_LAUNCH(2, 1, LL); break;                               \
+    }                                                                     \
   }
+  // instances: with / without the moving-sphere and triangle lists, with / without the grid walk
+  if (S.grid_mode) { if (lean) { CFT_LAUNCH_R(4) } else { CFT_LAUNCH_R(7) } }
+  else             { if (lean) { CFT_LAUNCH_R(0) } else { CFT_LAUNCH_R(3) } }
+#undef CFT_LAUNCH_R
 #undef CFT_LAUNCH
 }
 
@@ -663,6 +787,7 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
   cftrt_ctx* ctx = s->ctx;
   SceneDev S = s->dev;
   S.wave_cull = ctx->wave_cull;
+  S.grid_mode = S.gnx ? ctx->grid : 0;
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
   const bool phong = S.n_phong_mats > 0;
   const bool two_scans = S.any_motion && S.n_lights > 0;   // `looked` and trace each draw their own motion times
@@ -885,7 +1010,10 @@ int cftrt_intersect(cftrt_scene* s, const float* rays, uint64_t n, uint64_t seed
   char* base = (char*)ctx->misc.p;
   HIP_TRY(ctx, hipMemcpyAsync(base, rays, 24 * n, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(base + off_c, 0, 16, ctx->stream));
-  hipLaunchKernelGGL(k_intersect_hook, dim3(grid_for(ctx, n, 8)), dim3(CFT_BLOCK), 0, ctx->stream, s->dev,
+  SceneDev S = s->dev;
+  S.wave_cull = ctx->wave_cull;
+  S.grid_mode = S.gnx ? ctx->grid : 0;
+  hipLaunchKernelGGL(k_intersect_hook, dim3(grid_for(ctx, n, 8)), dim3(CFT_BLOCK), 0, ctx->stream, S,
                      (const float*)base, (uint32_t)n, pid0, level, role, (uint32_t)seed, (uint32_t)(seed >> 32),
                      (int32_t*)(base + off_id), (double*)(base + off_t), (float*)(base + off_n), (float*)(base + off_p),
                      (uint32_t*)(base + off_c));

@@ -207,7 +207,9 @@ __device__ __forceinline__ void cand_insert(Cand& c, float tlo, int idx) {
 // A sphere the fast path could not rule out (disc >= -E_ray): turn (q, disc) into a lower bound on its hit
 // distance, or -1 when it certainly is no hit nearer than U.
 //   q = oc.d,  disc = r^2 - |oc - q d|^2  (both f32, error model in DESIGN.md §4)
-__device__ __forceinline__ float sphere_lower_bound(const SceneDev& S, float q, float d, float U) {
+// thi (optional): an UPPER bound on the distance when the arithmetic can certify the hit (origin certainly outside
+// and approaching with a certainly positive discriminant, or origin certainly inside); untouched otherwise.
+__device__ __forceinline__ float sphere_lower_bound(const SceneDev& S, float q, float d, float U, float* thi = nullptr) {
   const float aq = fabsf(q);
   const float e = fmaf(aq, S.K1, S.K2);                 // |disc - true disc| <= e
   const float eq = fmaf(aq, S.K3, S.K4);                // |q - true q| <= eq
@@ -226,13 +228,26 @@ __device__ __forceinline__ float sphere_lower_bound(const SceneDev& S, float q, 
   tlo = tlo - eq - fabsf(tlo) * CFT_U4EPS;
   const bool possible = arg >= 0.0f && (inside || (s_hi - q + eq >= 0.0f));   // disc, t2 could be >= 0
   tlo = fmaxf(tlo, 0.0f);
+  if (thi) {
+    if (inside) {
+      // t2 <= -q + eq + sqrt(d + e)
+      const float sh = __builtin_amdgcn_sqrtf(d + e);
+      const float h = fmaf(sh, CFT_U4EPS, sh) - q + eq;
+      *thi = fmaf(fabsf(h), CFT_U4EPS, h);
+    } else if (io < -eio && q < -eq && d - e > 0.0f) {
+      // both roots positive; t1 <= -q + eq - sqrt(d - e)
+      const float sl = __builtin_amdgcn_sqrtf(d - e);
+      const float h = eq - q - fmaf(-sl, CFT_U4EPS, sl);
+      *thi = fmaf(fabsf(h), CFT_U4EPS, h);
+    }
+  }
   return (possible && tlo <= U) ? tlo : -1.0f;
 }
 
 // Moller-Trumbore in f32 with explicit error margins (triangle = p0, e1, e2): lower bound on the hit
 // distance, or -1.
 __device__ __forceinline__ float tri_lower_bound(const SceneDev& S, float ox, float oy, float oz, float dx, float dy,
-                                                 float dz, f3 p0, f3 e1, f3 e2, float U) {
+                                                 float dz, f3 p0, f3 e1, f3 e2, float U, float* thi = nullptr) {
   f3 d = mk3(dx, dy, dz);
   f3 h = cross3(d, e2);
   float a = dot3(e1, h);
@@ -251,6 +266,9 @@ __device__ __forceinline__ float tri_lower_bound(const SceneDev& S, float ox, fl
     if (u >= -mu && v >= -mu && u <= 1.0f + mu && u + v <= 1.0f + 2.0f * mu && t + mt > CFT_EPS) {
       float tlo = fmaxf(t - mt, 0.0f);
       if (tlo <= U) r = tlo;
+      // certainly a hit of the reference's test: |a| >= EPS, u, v, u + v inside by the margins, t > EPS
+      if (thi && fabsf(a) >= CFT_EPS + S.tKA && u >= mu && v >= mu && u + v <= 1.0f - 2.0f * mu && t - mt > CFT_EPS)
+        *thi = t + mt;
     }
   }
   return r;
@@ -324,19 +342,30 @@ __device__ __forceinline__ v2f pair_cull(v2f cxy, v2f czk, v2f dx, v2f dy, v2f d
 // (q, disc = r^2 - |oc - q d|^2), turn it into a lower bound and insert it.  Everything is scaled by 4 (16 for
 // squares), which is exact: 4 oc = 4 o' + 2 C is one rounding of the same real number as 4 (o' - c'), so
 // q4 = 4 q and d16 = 16 disc bit for bit.
-template <int R, int NS>
+// ONCE: the caller may offer the same primitive more than once (the grid walk: a primitive sits in every cell it
+// overlaps), and a primitive must not take two of the indexed slots.
+template <bool ONCE>
+__device__ __forceinline__ void cand_offer(Cand& c, float tlo, int idx) {
+  if (!ONCE || (idx != c.i1 && idx != c.i2)) cand_insert(c, tlo, idx);
+}
+
+template <int R, int NS, bool ONCE = false>
 __device__ __forceinline__ void sphere_candidate(const SceneDev& S, RayPack<R, NS>& P, int r, float Cx, float Cy,
-                                                 float Cz, float r2x16, int idx) {
+                                                 float Cz, float r2x16, int idx, float* hi = nullptr) {
   const float dx = PK(P, dx, r), dy = PK(P, dy, r), dz = PK(P, dz, r);
   float ocx = fmaf(2.0f, Cx, PK(P, o4x, r)), ocy = fmaf(2.0f, Cy, PK(P, o4y, r)), ocz = fmaf(2.0f, Cz, PK(P, o4z, r));
   float q4 = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
   float lx = fmaf(-q4, dx, ocx), ly = fmaf(-q4, dy, ocy), lz = fmaf(-q4, dz, ocz);
   float d16 = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, r2x16)));
   if (d16 >= P.negE16[r]) {
-    float tlo = sphere_lower_bound(S, 0.25f * q4, 0.0625f * d16, P.U[r]);
+    float thi = __builtin_inff();
+    float tlo = sphere_lower_bound(S, 0.25f * q4, 0.0625f * d16, P.U[r], hi ? &thi : nullptr);
     if (tlo >= 0.0f) {
 #pragma unroll
-      for (int k = 0; k < NS; ++k) cand_insert(P.c[k][r], tlo, idx);
+      for (int k = 0; k < NS; ++k) {
+        cand_offer<ONCE>(P.c[k][r], tlo, idx);
+        if (hi) hi[k] = fminf(hi[k], thi);
+      }
     }
   }
 }
@@ -464,8 +493,9 @@ __device__ __forceinline__ void scan_spheres_culled(const SceneDev& S, RayPack<R
 // A moving sphere whose swept bound the cull could not rule out for ray slot r (entry: 8 floats - centre at
 // time 0, r^2, moving_to, object id bits): per scan, the centre at that scan's motion time (object.rs:42-55),
 // the cancellation-free discriminant, the lower bound, the insert.
-template <int R, int NS>
-__device__ __forceinline__ void msphere_candidate(const SceneDev& S, RayPack<R, NS>& P, int r, v8f cur, int idx) {
+template <int R, int NS, bool ONCE = false>
+__device__ __forceinline__ void msphere_candidate(const SceneDev& S, RayPack<R, NS>& P, int r, v8f cur, int idx,
+                                                  float* hi = nullptr) {
   const uint32_t obj = __float_as_uint(cur[7]);
   const float dx = PK(P, dx, r), dy = PK(P, dy, r), dz = PK(P, dz, r);
   const float tx = 0.25f * PK(P, o4x, r), ty = 0.25f * PK(P, o4y, r), tz = 0.25f * PK(P, o4z, r);
@@ -478,8 +508,12 @@ __device__ __forceinline__ void msphere_candidate(const SceneDev& S, RayPack<R, 
     float lx = fmaf(-q, dx, ocx), ly = fmaf(-q, dy, ocy), lz = fmaf(-q, dz, ocz);
     float d = fmaf(-lz, lz, fmaf(-ly, ly, fmaf(-lx, lx, cur[3])));
     if (16.0f * d >= P.negE16[r]) {
-      float tlo = sphere_lower_bound(S, q, d, P.U[r]);
-      if (tlo >= 0.0f) cand_insert(P.c[k][r], tlo, idx);
+      float thi = __builtin_inff();
+      float tlo = sphere_lower_bound(S, q, d, P.U[r], hi ? &thi : nullptr);
+      if (tlo >= 0.0f) {
+        cand_offer<ONCE>(P.c[k][r], tlo, idx);
+        if (hi) hi[k] = fminf(hi[k], thi);
+      }
     }
   }
 }
@@ -507,11 +541,140 @@ __device__ __forceinline__ void scan_msphere(const SceneDev& S, RayPack<R, NS>& 
   }
 }
 
+// ------------------------------------------------------------------ uniform grid (an extension: the reference scans linearly)
+// Static spheres, the swept bounds of moving spheres and static triangles are also registered in a uniform grid
+// over their bounding box (cftrt_scene_commit).  A wave whose bundle is too wide for the cone cull walks the grid
+// instead of the lists: every lane takes its own ray through the cells it crosses (3D DDA) and tests the
+// primitives registered there with the same f32 tests as the list scan, so the candidate sets, and with them the
+// exact f64 result, are those of the full scan:
+//  * the walk is the exact walk of the ray through a grid whose planes are displaced by rounding (a few ulp of
+//    the box size per plane, plus the accumulated tMax rounding: < 1e-4 of the box half-extent E for origins
+//    within 4 E); every primitive is registered with its bound inflated by 1e-3 E, so a primitive the ray hits is
+//    met in one of the visited cells;
+//  * the walk ends where it leaves the box, passes the ray's upper bound U (the exact precise-sphere hit), or
+//    passes the upper bound of a candidate that certainly is a hit (the f32 error bounds can certify most hits).
+//    In the last case the primitives not met are all farther than the exit of the last cell; that distance also
+//    becomes the ray's third bound lo3, so the epilogue would rescan in f64 if the exact result did not beat it
+//    (ray_epilogue) - the stop needs no trust in the certificate.
+// Rays that start farther than 4 E from the scene centre are not walked (the wave scans the lists).
+template <int R, int NS, int LISTS>
+__device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>& P, int r) {
+  const float inf = __builtin_inff();
+  const float dx = PK(P, dx, r), dy = PK(P, dy, r), dz = PK(P, dz, r);
+  const float ox = 0.25f * PK(P, o4x, r), oy = 0.25f * PK(P, o4y, r), oz = 0.25f * PK(P, o4z, r);
+  // reciprocals that stay finite (a zero component never reaches a plane: |t| ~ 1e30 * distance)
+  const float ix_ = __builtin_amdgcn_rcpf(fabsf(dx) < 1e-30f ? copysignf(1e-30f, dx) : dx);
+  const float iy_ = __builtin_amdgcn_rcpf(fabsf(dy) < 1e-30f ? copysignf(1e-30f, dy) : dy);
+  const float iz_ = __builtin_amdgcn_rcpf(fabsf(dz) < 1e-30f ? copysignf(1e-30f, dz) : dz);
+  // slab clip against the (inflated) box
+  const float ax0 = (S.g0x - ox) * ix_, ax1 = (S.g1x - ox) * ix_;
+  const float ay0 = (S.g0y - oy) * iy_, ay1 = (S.g1y - oy) * iy_;
+  const float az0 = (S.g0z - oz) * iz_, az1 = (S.g1z - oz) * iz_;
+  const float t0 = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fmaxf(fminf(az0, az1), 0.0f));
+  const float texit = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fmaxf(az0, az1));
+  const float tend = fminf(texit, fmaf(P.U[r], 1.0001f, 1e-4f));
+  if (!(t0 <= tend)) return;   // misses the box, or the box lies beyond U
+  // entry cell
+  int cx = (int)floorf((fmaf(dx, t0, ox) - S.g0x) * S.gicx), cy = (int)floorf((fmaf(dy, t0, oy) - S.g0y) * S.gicy),
+      cz = (int)floorf((fmaf(dz, t0, oz) - S.g0z) * S.gicz);
+  cx = min(max(cx, 0), S.gnx - 1); cy = min(max(cy, 0), S.gny - 1); cz = min(max(cz, 0), S.gnz - 1);
+  // distance to the next plane of each axis, and between planes (signed like the direction: the step)
+  float tmx = (fmaf((float)(cx + (dx >= 0.0f ? 1 : 0)), S.gcsx, S.g0x) - ox) * ix_;
+  float tmy = (fmaf((float)(cy + (dy >= 0.0f ? 1 : 0)), S.gcsy, S.g0y) - oy) * iy_;
+  float tmz = (fmaf((float)(cz + (dz >= 0.0f ? 1 : 0)), S.gcsz, S.g0z) - oz) * iz_;
+  const float sdx = S.gcsx * ix_, sdy = S.gcsy * iy_, sdz = S.gcsz * iz_;
+  const int stx = dx >= 0.0f ? 1 : -1, sty = dy >= 0.0f ? 1 : -1, stz = dz >= 0.0f ? 1 : -1;
+  int guard = S.gnx + S.gny + S.gnz + 3;
+  float hi[NS];        // per scan: smallest upper bound among the candidates that certainly are hits
+#pragma unroll
+  for (int k = 0; k < NS; ++k) hi[k] = inf;
+  float tstop = inf;   // lower bound on the distance of every primitive the walk did not meet
+  const uint4* cells = S.gridCell;
+  while (true) {
+    const uint4 cell = cells[(uint32_t)((cz * S.gny + cy) * S.gnx + cx)];
+    for (uint32_t e = cell.x, ee = cell.x + cell.y; e < ee; ++e) {
+      const float4 a = S.gridSph[2 * e];
+      // the per-ray cull of scan_sphere, unpacked (same operations in the same order)
+      float q = fmaf(a.z, dz, PK(P, od2, r)), c = fmaf(a.z, PK(P, o4z, r), PK(P, thr4, r));
+      q = fmaf(a.y, dy, q); c = fmaf(a.y, PK(P, o4y, r), c);
+      q = fmaf(a.x, dx, q); c = fmaf(a.x, PK(P, o4x, r), c);
+      if (fmaf(q, q, -c) >= a.w) {
+        const float4 b = S.gridSph[2 * e + 1];
+        const int idx = __float_as_int(b.y);
+        if (!(LISTS & 1) || idx < S.n_sphF) {
+          sphere_candidate<R, NS, true>(S, P, r, a.x, a.y, a.z, b.x, idx, hi);
+        } else {
+          const float4 m0 = S.msphF[2 * (idx - S.n_sphF)], m1 = S.msphF[2 * (idx - S.n_sphF) + 1];
+          msphere_candidate<R, NS, true>(S, P, r, v8f{m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w}, idx, hi);
+        }
+      }
+    }
+    if (LISTS & 2) {
+      for (uint32_t e = cell.z, ee = cell.z + cell.w; e < ee; ++e) {
+        const int s = (int)S.gridTri[e];
+        const float4 p0 = S.triF[3 * s], e1 = S.triF[3 * s + 1], e2 = S.triF[3 * s + 2];
+        float thi = inf;
+        const float tlo = tri_lower_bound(S, ox, oy, oz, dx, dy, dz, mk3(p0.x, p0.y, p0.z), mk3(e1.x, e1.y, e1.z),
+                                          mk3(e2.x, e2.y, e2.z), P.U[r], &thi);
+        if (tlo >= 0.0f) {
+#pragma unroll
+          for (int k = 0; k < NS; ++k) {
+            cand_offer<true>(P.c[k][r], tlo, S.n_sphF + S.n_msph + s);
+            hi[k] = fminf(hi[k], thi);
+          }
+        }
+      }
+    }
+    const float tn = fminf(tmx, fminf(tmy, tmz));   // exit of this cell
+    if (!(tn <= tend)) break;                       // out of the box or beyond U: nothing left that could win
+    float best = hi[0];
+#pragma unroll
+    for (int k = 1; k < NS; ++k) best = fmaxf(best, hi[k]);
+    const float tcut = fmaf(tn, 0.9999f, -1e-4f);   // every primitive not met is farther than this
+    if (tcut > best || --guard < 0) {
+      // a certain hit nearer than everything not met: stop (guard: cannot happen; the rescan then decides)
+      tstop = guard < 0 ? 0.0f : tcut;
+      break;
+    }
+    // step into the neighbour across the nearest plane (straight-line: three-way branches diverge)
+    const bool ax = tmx <= tmy && tmx <= tmz, ay = !ax && tmy <= tmz, az = !ax && !ay;
+    cx += ax ? stx : 0; cy += ay ? sty : 0; cz += az ? stz : 0;
+    tmx += ax ? fabsf(sdx) : 0.0f; tmy += ay ? fabsf(sdy) : 0.0f; tmz += az ? fabsf(sdz) : 0.0f;
+    if ((unsigned)cx >= (unsigned)S.gnx || (unsigned)cy >= (unsigned)S.gny || (unsigned)cz >= (unsigned)S.gnz) break;
+  }
+#pragma unroll
+  for (int k = 0; k < NS; ++k) P.c[k][r].lo3 = fminf(P.c[k][r].lo3, tstop);
+}
+
+// Moving triangles (4 float4 each: p0, e1, e2, (mv, object id)), once per scan with that scan's motion time.
+template <int R, int NS>
+__device__ __forceinline__ void scan_mtris(const SceneDev& S, RayPack<R, NS>& P, int base, int part, int nparts) {
+  if (!S.n_mtri) return;
+  c_f4p tp = AS_CONST(c_f4p, S.mtriF);
+  for (int s = S.n_mtri * part / nparts; s < S.n_mtri * (part + 1) / nparts; ++s) {
+    v4f a = tp[4 * s], b = tp[4 * s + 1], cc = tp[4 * s + 2], m = tp[4 * s + 3];
+    const uint32_t obj = __float_as_uint(m.w);
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float tm = motion_time(P.word[k][r], obj);
+        float tlo = tri_lower_bound(S, 0.25f * PK(P, o4x, r), 0.25f * PK(P, o4y, r), 0.25f * PK(P, o4z, r), PK(P, dx, r),
+                                    PK(P, dy, r), PK(P, dz, r),
+                                    mk3(fmaf(m.x, tm, a.x), fmaf(m.y, tm, a.y), fmaf(m.z, tm, a.z)),
+                                    mk3(b.x, b.y, b.z), mk3(cc.x, cc.y, cc.z), P.U[r]);
+        if (tlo >= 0.0f) cand_insert(P.c[k][r], tlo, base + s);
+      }
+    }
+  }
+}
+
 // f32 scan of every non-precise primitive for R rays (indices into [sphF | msph | triF | mtri]).
 // part / nparts (wave-uniform): this wave scans the part-th slice of each list (nparts = 1: all of it).
 // WCULL: try the wave-level cull first (the R-rays-per-lane kernels; every lane of the wave must be active).
-// LISTS (compile time): 1 = the scene may hold moving spheres, 2 = triangles; a scene of static spheres only runs
-// kernels without that code (and its registers).
+// LISTS (compile time): 1 = the scene may hold moving spheres, 2 = triangles, 4 = the scene has a grid and the ctx
+// uses it; a scene of static spheres only, or a pass on the plain lists, runs kernels without the other code (and
+// its registers).
 template <int R, int NS, bool WCULL = false, int LISTS = 3>
 __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P, int part = 0, int nparts = 1) {
   const int n4_all = (S.n_sphF + 3) >> 2;
@@ -522,6 +685,25 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P,
     B = wave_bundle<R, NS>(P);
     if (!B.live) return;          // no live ray in this wave
     cull = B.narrow;              // wider than ~37 degrees: scan the whole lists
+  }
+  // the grid instead of the lists (mode 1: for waves the cone cull does not serve; 2: for every wave), unless a
+  // ray of the wave starts too far out for the walk's error bounds
+  bool grid = false;
+  if ((LISTS & 4) && nparts == 1 && S.grid_mode && (S.grid_mode == 2 || !cull)) {
+    bool far = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (PK(P, thr4, r) < __builtin_inff())
+        far |= fmaxf(fabsf(PK(P, o4x, r)), fmaxf(fabsf(PK(P, o4y, r)), fabsf(PK(P, o4z, r)))) > S.gfar4;
+    grid = __builtin_amdgcn_ballot_w64(far) == 0ull;
+  }
+  if (grid) {
+    // moving triangles are not in the grid; the walk comes last (it may lower lo3 below lo2, which no insert may follow)
+    if (LISTS & 2) scan_mtris<R, NS>(S, P, S.n_sphF + S.n_msph + S.n_triF, 0, 1);
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (PK(P, thr4, r) < __builtin_inff()) grid_walk_ray<R, NS, LISTS>(S, P, r);
+    return;
   }
   if (cull) {
     scan_spheres_culled<R, NS>(S, P, B, lo4 << 2, min(hi4 << 2, S.n_sphF));
@@ -628,25 +810,7 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P,
     }
   }
   base += S.n_triF;
-  if ((LISTS & 2) && S.n_mtri) {   // moving triangles, 4 float4 each: p0, e1, e2, (mv, object id)
-    c_f4p tp = AS_CONST(c_f4p, S.mtriF);
-    for (int s = S.n_mtri * part / nparts; s < S.n_mtri * (part + 1) / nparts; ++s) {
-      v4f a = tp[4 * s], b = tp[4 * s + 1], cc = tp[4 * s + 2], m = tp[4 * s + 3];
-      const uint32_t obj = __float_as_uint(m.w);
-#pragma unroll
-      for (int k = 0; k < NS; ++k) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          float tm = motion_time(P.word[k][r], obj);
-          float tlo = tri_lower_bound(S, 0.25f * PK(P, o4x, r), 0.25f * PK(P, o4y, r), 0.25f * PK(P, o4z, r), PK(P, dx, r),
-                                      PK(P, dy, r), PK(P, dz, r),
-                                      mk3(fmaf(m.x, tm, a.x), fmaf(m.y, tm, a.y), fmaf(m.z, tm, a.z)),
-                                      mk3(b.x, b.y, b.z), mk3(cc.x, cc.y, cc.z), P.U[r]);
-          if (tlo >= 0.0f) cand_insert(P.c[k][r], tlo, base + s);
-        }
-      }
-    }
-  }
+  if (LISTS & 2) scan_mtris<R, NS>(S, P, base, part, nparts);
 }
 
 __device__ __forceinline__ int list_to_gid(const SceneDev& S, int i) {
@@ -736,7 +900,7 @@ __device__ __forceinline__ Closest closest_hit(const SceneDev& S, float ox, floa
   Closest pre = precise_hit(S, ox, oy, oz, dx, dy, dz, scan_word);
   ray_setup<1, 1>(S, P, 0, ox, oy, oz, dx, dy, dz, pre);
   pack_dummy_slot<1, 1>(P, 1);
-  scan_lists<1, 1>(S, P);
+  scan_lists<1, 1, false, 7>(S, P);
   return ray_epilogue(S, ox, oy, oz, dx, dy, dz, scan_word, P.c[0][0], pre, stats);
 }
 

@@ -41,6 +41,15 @@ struct SceneDev {
   const float4* mtriF;    // moving triangles, 4 float4 each: p0, e1, e2, (mv, object id bits)
   const int* mtri_gid;
   int n_mtri;
+  // ---- uniform grid over the lists above (an extension; 0 cells = none).  Cell (x, y, z) -> gridCell[(z*gny + y)*gnx + x]
+  const uint4* gridCell;  // (first sphere entry, count, first triangle entry, count)
+  const float4* gridSph;  // 2 float4 per entry: the sphF / msphB entry, then (16 r^2, list index bits, -, -)
+  const uint32_t* gridTri;   // index into triF
+  int gnx, gny, gnz;
+  int grid_mode;          // 0: lists only; 1: waves too wide for the cone cull walk the grid; 2: every wave does
+  float g0x, g0y, g0z, g1x, g1y, g1z;   // the (inflated) box, relative to the scene centre
+  float gcsx, gcsy, gcsz, gicx, gicy, gicz;   // cell size and its inverse
+  float gfar4;            // 4 * the largest |coordinate| of a ray origin the walk accepts
   // ---- f64 master copies (exact evaluation) ----
   const double* sphD;     // n_sph x 4: cx, cy, cz, r
   const double* sphMvD;   // n_sph x 3 (all zero for static spheres)

@@ -1,0 +1,19 @@
+"""Per-launch durations of the level kernels from a rocprofv3 --kernel-trace CSV (last frame of the run).
+usage: level_times.py DIR   (DIR holds *_kernel_trace.csv)"""
+import csv, glob, sys
+f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
+rows = [r for r in csv.DictReader(open(f))]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+# frames are separated by k_generate launches
+frames, cur = [], None
+for r in rows:
+    n = r["Kernel_Name"]
+    if "k_generate" in n:
+        cur = []
+        frames.append(cur)
+    elif cur is not None and ("k_trace" in n or "k_intersect" in n or "k_shade" in n):
+        cur.append((n.split("(")[0][:40], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+last = frames[-1]
+tot = sum(d for _, d in last)
+print("launches", len(last), "total_us", round(tot, 1))
+print(" ".join(f"{d:.0f}" for _, d in last))

@@ -427,6 +427,76 @@ def test_wave_cull_random_scenes(rt, seed):
     assert int(sa.rays) > 2 * W * H * 4          # paths do bounce
 
 
+def _random_world(rt, seed):
+    """Random world of the wave-cull / grid tests: spheres from pebbles to boulders, a negative radius, moving
+    spheres, triangles, squares, a cube, mirrors and glass; camera inside the cloud."""
+    rng = np.random.default_rng(1000 + seed)
+    A = rt
+    world = A.World.empty()
+    mats = [A.LambertianModel(0.9).with_color((0.8, 0.6, 0.4)), A.Metal(0.0, 0.95), A.Metal(0.2, 0.9).with_color((0.9, 0.9, 1.0)),
+            A.Dielectric(1.5), A.Specular(0.9), A.Transparent(0.3, 1.3)]
+    world.add_obj(A.Object(A.Sphere((0.0, 0.0, -300.0), 300.0), mats[0]))
+    for i in range(150):
+        c = tuple(rng.uniform(-8, 8, 2)) + (float(rng.uniform(0.0, 3.0)),)
+        r = float(rng.choice([0.05, 0.2, 0.5, 1.5]) * rng.uniform(0.5, 1.5))
+        if i == 7:
+            r = -r
+        o = A.Object(A.Sphere(c, r), mats[int(rng.integers(len(mats)))])
+        if i % 5 == 0:
+            o = o.moved(tuple(rng.uniform(-0.5, 0.5, 3)))
+        world.add_obj(o)
+    for i in range(40):
+        p = rng.uniform(-8, 8, 3); p[2] = abs(p[2]) * 0.4
+        world.add_obj(A.Object(A.Triangle(tuple(p), tuple(p + rng.uniform(-1.5, 1.5, 3)), tuple(p + rng.uniform(-1.5, 1.5, 3))),
+                               mats[int(rng.integers(len(mats)))]))
+    world.add_obj(A.Object(A.Square((2.0, 1.0, 1.0), (1.0, 0.0, 0.0), (0.0, 0.6, 0.8), 1.2), mats[1]))
+    world.add_obj(A.Object(A.Cube((-3.0, 2.0, 0.6), (1.0, 0.2, 0.0), (-0.2, 1.0, 0.0), 1.0), mats[3]))
+    world.add_light(A.SkyLight())
+    cam = (A.Camera.new((6.0, -5.0, 1.5), (0.0, 0.0, 0.8)).with_fov(50.0).with_aspect(2.0).with_aperture(0.05)
+           .with_focus_dist(7.0).with_sample_rate(4))
+    return world, cam
+
+
+@pytest.mark.parametrize("name,W,H,spp,depth", [("s500", 640, 360, 4, 50), ("s500", 96, 54, 8, 50), ("scene_rs", 320, 200, 4, 10),
+                                                 ("s20k", 320, 184, 2, 8)])
+def test_grid_is_exact(rt, name, W, H, spp, depth):
+    """The uniform grid (an extension: the reference scans linearly) only changes WHICH primitives a ray tests; the
+    candidates go through the same exact evaluation, and a walk that stops early makes the epilogue rescan whenever
+    an untested primitive could still win.  So the image and the ray counts with the grid (mode 1: wide bundles,
+    mode 2: every wave) must equal those of the plain lists (mode 0) bit for bit."""
+    world, cam = getattr(rt.scenes, {"s500": "s500", "scene_rs": "scene_rs", "s20k": "s20k"}[name])()
+    dev = rt.default_device()
+    out = {}
+    try:
+        for mode in (0, 1, 2):
+            dev.set_grid(mode)
+            out[mode] = world.render(cam, W, H, depth, spp_begin=0, spp_end=spp, return_stats=True)
+    finally:
+        dev.set_grid(1)
+    for mode in (1, 2):
+        assert np.array_equal(out[0][0], out[mode][0])
+        assert list(out[0][1].rays_per_level[: int(out[0][1].levels)]) == list(out[mode][1].rays_per_level[: int(out[mode][1].levels)])
+
+
+@pytest.mark.parametrize("seed,cells", [(1, 0.5), (2, 4.0), (3, 32.0), (4, 4.0)])
+def test_grid_random_scenes(rt, seed, cells):
+    """Random worlds with moving spheres (registered by their swept bounds) and triangles, at three grid
+    resolutions (a fresh commit each: the resolution is fixed at commit): lists and grid agree bit for bit."""
+    dev = rt.default_device()
+    W, H, depth = 256, 128, 12
+    out = {}
+    try:
+        for mode in (0, 1, 2):
+            world, cam = _random_world(rt, seed)
+            dev.set_grid(mode, cells)
+            out[mode] = world.render(cam, W, H, depth, seed=seed, return_stats=True)
+    finally:
+        dev.set_grid(1, 4.0)
+    for mode in (1, 2):
+        assert np.array_equal(out[0][0], out[mode][0])
+        assert list(out[0][1].rays_per_level[: int(out[0][1].levels)]) == list(out[mode][1].rays_per_level[: int(out[mode][1].levels)])
+
+
 def test_full_size_properties(rt, orc):
     """BASELINE.json configs[2] at full size (1920x1080, 64 spp, depth 50): size-independent properties."""
     world, cam = rt.scenes.s500()
