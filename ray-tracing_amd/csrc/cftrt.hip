@@ -394,6 +394,56 @@ int cftrt_scene_commit(cftrt_scene* s) {
       triF_gid.push_back(ns + i);
     }
   }
+  // Primitives much larger than the rest (the three r = 1 spheres of scene.rs among r = 0.2 ones, the walls of a room)
+  // would stretch the grid's box and sit in a great many cells.  Each list is reordered so that they come first:
+  // with the grid on, that short prefix is scanned linearly by every ray and only the rest goes into the grid.
+  // Big = extent above 4x the median extent, at most 64 per scene (the largest ones).  List order is free: exact
+  // ties are broken by object id, not by position.
+  int nb_sph = 0, nb_msph = 0, nb_tri = 0;
+  {
+    const int nS = (int)sphF_gid.size(), nM = (int)msph_gid.size(), nT = (int)triF_gid.size();
+    std::vector<double> ext((size_t)(nS + nM + nT));
+    for (int i = 0; i < nS; ++i) ext[i] = 0.5 * std::sqrt((double)sphR2[i]);
+    for (int i = 0; i < nM; ++i) ext[nS + i] = 2. * msph_rb[i];
+    for (int i = 0; i < nT; ++i) {
+      const float4 e1 = triF[3 * i + 1], e2 = triF[3 * i + 2];
+      double m = 0.;
+      const double ex[3][2] = {{e1.x, e2.x}, {e1.y, e2.y}, {e1.z, e2.z}};
+      for (int k = 0; k < 3; ++k)
+        m = std::max(m, std::max(0., std::max(ex[k][0], ex[k][1])) - std::min(0., std::min(ex[k][0], ex[k][1])));
+      ext[nS + nM + i] = m;
+    }
+    if (ext.size() >= 64) {
+      std::vector<double> sorted(ext);
+      std::nth_element(sorted.begin(), sorted.begin() + sorted.size() / 2, sorted.end());
+      double thr = 4. * sorted[sorted.size() / 2];
+      std::vector<double> bigs;
+      for (double e : ext) if (e > thr) bigs.push_back(e);
+      if (bigs.size() > 64) {
+        std::nth_element(bigs.begin(), bigs.end() - 64, bigs.end());
+        thr = std::max(thr, *(bigs.end() - 64));
+      }
+      // stable partition of each list, big first
+      auto order = [&](int base, int n, int* nb) {
+        std::vector<int> o;
+        for (int i = 0; i < n; ++i) if (ext[base + i] > thr) o.push_back(i);
+        *nb = (int)o.size();
+        for (int i = 0; i < n; ++i) if (!(ext[base + i] > thr)) o.push_back(i);
+        return o;
+      };
+      auto apply = [](const std::vector<int>& o, auto& v, int per) {
+        auto old = v;
+        for (size_t i = 0; i < o.size(); ++i)
+          for (int k = 0; k < per; ++k) v[per * i + k] = old[per * (size_t)o[i] + k];
+      };
+      std::vector<int> o = order(0, nS, &nb_sph);
+      apply(o, sphF, 1); apply(o, sphR2, 1); apply(o, sphF_gid, 1);
+      o = order(nS, nM, &nb_msph);
+      apply(o, msphF, 2); apply(o, msphB, 1); apply(o, msph_rb, 1); apply(o, msph_gid, 1);
+      o = order(nS + nM, nT, &nb_tri);
+      apply(o, triF, 3); apply(o, triF_gid, 1);
+    }
+  }
   msphF.push_back(make_float4(0.f, 0.f, 0.f, -1e30f));   // the prefetched extra entry of the moving list
   msphF.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
   while (msphB.size() % 4) msphB.push_back(make_float4(0.f, 0.f, 0.f, 1e30f));
@@ -408,12 +458,15 @@ int cftrt_scene_commit(cftrt_scene* s) {
   // such primitives, or whose primitives are large against any sensible cell (a Cornell box), get no grid.
   std::vector<uint4> gridCell;
   std::vector<float4> gridSph;
+  std::vector<float2> gridSphX;
   std::vector<uint32_t> gridTri;
   struct { int n[3]; double lo[3], hi[3], cs[3], far; } G = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, 0};
   {
     const int nS = n_sphF_real, nM = (int)msph_gid.size(), nT = (int)triF_gid.size(), nP = nS + nM + nT;
     struct Box { double lo[3], hi[3]; };
     std::vector<Box> bx((size_t)nP);
+    auto in_grid = [&](int i) { return i < nS ? i >= nb_sph : (i < nS + nM ? i - nS >= nb_msph : i - nS - nM >= nb_tri); };
+    const int nG = nP - nb_sph - nb_msph - nb_tri;   // primitives that go into the grid
     std::vector<double> cen(3 * (size_t)(nS + nM)), rad((size_t)(nS + nM));
     for (int i = 0; i < nS + nM; ++i) {
       const float4 e = i < nS ? sphF[i] : msphB[i - nS];
@@ -432,15 +485,15 @@ int cftrt_scene_commit(cftrt_scene* s) {
         b.hi[k] = std::max(v[0][k], std::max(v[1][k], v[2][k]));
       }
     }
-    if (nP >= 64) {
+    if (nG >= 64) {
       double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
-      for (const Box& b : bx) for (int k = 0; k < 3; ++k) { blo[k] = std::min(blo[k], b.lo[k]); bhi[k] = std::max(bhi[k], b.hi[k]); }
+      for (int i = 0; i < nP; ++i) if (in_grid(i)) for (int k = 0; k < 3; ++k) { blo[k] = std::min(blo[k], bx[i].lo[k]); bhi[k] = std::max(bhi[k], bx[i].hi[k]); }
       double E = 0.;
       for (int k = 0; k < 3; ++k) E = std::max(E, std::max(std::fabs(blo[k]), std::fabs(bhi[k])));
       const double margin = 1e-3 * E;
       double ext[3], vol = 1.;
       for (int k = 0; k < 3; ++k) { blo[k] -= 2. * margin; bhi[k] += 2. * margin; ext[k] = bhi[k] - blo[k]; vol *= ext[k]; }
-      double cell = std::cbrt(vol / (ctx->grid_density * nP));
+      double cell = std::cbrt(vol / (ctx->grid_density * nG));
       for (int attempt = 0; attempt < 4 && !G.n[0]; ++attempt, cell *= 2.) {
         int n[3];
         double cs[3];
@@ -475,30 +528,31 @@ int cftrt_scene_commit(cftrt_scene* s) {
                 f(((size_t)z * n[1] + y) * n[0] + x);
               }
         };
-        for (int i = 0; i < nP; ++i) each_cell(i, [&](size_t c) { (i < nS + nM ? cntS : cntT)[c]++; total++; });
-        if (total > 24 * (size_t)nP) continue;   // primitives much larger than the cells: coarser
+        for (int i = 0; i < nP; ++i) if (in_grid(i)) each_cell(i, [&](size_t c) { (i < nS + nM ? cntS : cntT)[c]++; total++; });
+        if (total > 24 * (size_t)nG) continue;   // primitives much larger than the cells: coarser
         gridCell.resize(nc);
         uint32_t oS = 0, oT = 0;
         for (size_t c = 0; c < nc; ++c) { gridCell[c] = make_uint4(oS, 0, oT, 0); oS += cntS[c]; oT += cntT[c]; }
-        gridSph.resize(2 * (size_t)oS);
+        gridSph.resize((size_t)oS);
+        gridSphX.resize((size_t)oS);
         gridTri.resize(oT);
         for (int i = 0; i < nP; ++i)
-          each_cell(i, [&](size_t c) {
+          if (in_grid(i)) each_cell(i, [&](size_t c) {
             if (i < nS + nM) {
               const size_t e = (size_t)gridCell[c].x + gridCell[c].y++;
               float ib;
               memcpy(&ib, &i, 4);
-              gridSph[2 * e] = i < nS ? sphF[i] : msphB[i - nS];
-              gridSph[2 * e + 1] = make_float4(i < nS ? sphR2[i] : 0.f, ib, 0.f, 0.f);
+              gridSph[e] = i < nS ? sphF[i] : msphB[i - nS];
+              gridSphX[e] = make_float2(i < nS ? sphR2[i] : 0.f, ib);
             } else {
               gridTri[(size_t)gridCell[c].z + gridCell[c].w++] = (uint32_t)(i - nS - nM);
             }
           });
         for (int k = 0; k < 3; ++k) { G.n[k] = n[k]; G.lo[k] = blo[k]; G.hi[k] = bhi[k]; G.cs[k] = cs[k]; }
-        G.far = 4. * E;
+        G.far = 256. * E;
       }
     }
-    if (gridSph.empty()) gridSph.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
+    if (gridSph.empty()) { gridSph.push_back(make_float4(0.f, 0.f, 0.f, 0.f)); gridSphX.push_back(make_float2(0.f, 0.f)); }
     if (gridTri.empty()) gridTri.push_back(0u);
     if (gridCell.empty()) gridCell.push_back(make_uint4(0, 0, 0, 0));
   }
@@ -532,6 +586,7 @@ int cftrt_scene_commit(cftrt_scene* s) {
   if ((rc = upload(s, mtri_gid, &D.mtri_gid))) return rc;
   if ((rc = upload(s, gridCell, &D.gridCell))) return rc;
   if ((rc = upload(s, gridSph, &D.gridSph))) return rc;
+  if ((rc = upload(s, gridSphX, &D.gridSphX))) return rc;
   if ((rc = upload(s, gridTri, &D.gridTri))) return rc;
   if ((rc = upload(s, sphD, &D.sphD))) return rc;
   if ((rc = upload(s, s->sph_mv, &D.sphMvD))) return rc;
@@ -556,6 +611,7 @@ int cftrt_scene_commit(cftrt_scene* s) {
   D.prec_motion = prec_motion;
   D.n_phong_mats = n_phong;
   D.gnx = G.n[0]; D.gny = G.n[1]; D.gnz = G.n[2];
+  D.nb_sph = nb_sph; D.nb_msph = nb_msph; D.nb_tri = nb_tri;
   D.grid_mode = 0;   // set per pass from the ctx (cftrt_ctx_set_grid)
   if (G.n[0]) {
     // the box as the kernel sees it: low corner rounded down, high corner up (the box only grows)

@@ -128,23 +128,52 @@ __device__ __forceinline__ bool exact_prim(const SceneDev& S, int g, d3 o, d3 d,
   return exact_tri(o, d, p0, p1, p2, t_out);
 }
 
-// Ray::hit in f64 over every primitive (the fallback when the f32 cull cannot decide).
-// Lowest object index wins exact ties (min_by keeps the first minimum, ray.rs:23-27).
-__device__ __forceinline__ void exact_scan_all(const SceneDev& S, d3 o, d3 d, uint32_t scan_word, double* T,
-                                            int* G) {
-  double bt = __builtin_inf();
-  int bg = -1, bobj = 0x7fffffff;
-  int n = S.n_sph + S.n_tri;
-  for (int g = 0; g < n; ++g) {
-    double t;
-    if (!exact_prim(S, g, o, d, scan_word, &t)) continue;
-    int obj = S.prim_obj[g];
-    if (t < bt || (t == bt && obj < bobj)) {
-      bt = t; bg = g; bobj = obj;
+// Ray::hit in f64 over every primitive (the fallback when the f32 cull cannot decide); lowest object index wins
+// exact ties (min_by keeps the first minimum, ray.rs:23-27).  Done by the whole wave: `want` lanes ask for it (rarely: a third candidate within reach, or a grid
+// walk that stopped early on a hit the exact arithmetic then refuses).  One lane alone needs ~90 ns per primitive -
+// 1.8 ms in a 20 k primitive scene, and the launch waits for it - so the lanes that are active here take the
+// requests one by one, each testing every nact-th primitive; the per-lane winners are then compared in the order
+// (t, object id, prim id) - what a serial loop over ascending prim ids with a strict compare realises.  Must be reached by the requesting
+// lanes together (any set of other lanes may be inactive: fewer helpers).
+__device__ __forceinline__ void exact_scan_all_wave_call(const SceneDev& S, bool want, d3 o, d3 d, uint32_t scan_word,
+                                                     double* T, int* G) {
+  const unsigned long long act = __ballot(1);
+  unsigned long long need = __ballot(want);
+  const int lane = (int)(threadIdx.x & 63u);
+  const int nact = __popcll(act), rank = __popcll(act & ((1ull << lane) - 1ull));
+  const int n = S.n_sph + S.n_tri;
+#define CFT_BCAST_D(x, src) __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), src), __builtin_amdgcn_readlane(__double2loint(x), src))
+  while (need) {
+    const int src = (int)__builtin_ctzll(need);
+    need &= need - 1ull;
+    const d3 ro = d3{CFT_BCAST_D(o.x, src), CFT_BCAST_D(o.y, src), CFT_BCAST_D(o.z, src)};
+    const d3 rd = d3{CFT_BCAST_D(d.x, src), CFT_BCAST_D(d.y, src), CFT_BCAST_D(d.z, src)};
+    const uint32_t rw = (uint32_t)__builtin_amdgcn_readlane((int)scan_word, src);
+    double bt = __builtin_inf();
+    int bg = 0x7fffffff, bobj = 0x7fffffff;
+    for (int g = rank; g < n; g += nact) {
+      double t;
+      if (!exact_prim(S, g, ro, rd, rw, &t)) continue;
+      const int obj = S.prim_obj[g];
+      if (t < bt || (t == bt && obj < bobj)) { bt = t; bg = g; bobj = obj; }   // g ascends: the first of equals stays
     }
+    // the winners of the active lanes, one by one (uniform values; every lane ends with the same result)
+    double wt = __builtin_inf();
+    int wg = 0x7fffffff, wobj = 0x7fffffff;
+    for (unsigned long long m = act; m; m &= m - 1ull) {
+      const int l = (int)__builtin_ctzll(m);
+      const double lt = CFT_BCAST_D(bt, l);
+      const int lg = __builtin_amdgcn_readlane(bg, l), lobj = __builtin_amdgcn_readlane(bobj, l);
+      if (lt < wt || (lt == wt && (lobj < wobj || (lobj == wobj && lg < wg)))) { wt = lt; wg = lg; wobj = lobj; }
+    }
+    if (lane == src) { *T = wt; *G = wt < __builtin_inf() ? wg : -1; }
   }
-  *T = bt;
-  *G = bg;
+#undef CFT_BCAST_D
+}
+
+__device__ __forceinline__ void exact_scan_all_wave(const SceneDev& S, bool want, d3 o, d3 d, uint32_t scan_word,
+                                                    double* T, int* G) {
+  if (__ballot(want)) exact_scan_all_wave_call(S, want, o, d, scan_word, T, G);
 }
 
 // Geometric unit normal of prim g at point p (before HitInfo::new's flip):
@@ -549,14 +578,14 @@ __device__ __forceinline__ void scan_msphere(const SceneDev& S, RayPack<R, NS>& 
 // exact f64 result, are those of the full scan:
 //  * the walk is the exact walk of the ray through a grid whose planes are displaced by rounding (a few ulp of
 //    the box size per plane, plus the accumulated tMax rounding: < 1e-4 of the box half-extent E for origins
-//    within 4 E); every primitive is registered with its bound inflated by 1e-3 E, so a primitive the ray hits is
+//    within 256 E); every primitive is registered with its bound inflated by 1e-3 E, so a primitive the ray hits is
 //    met in one of the visited cells;
 //  * the walk ends where it leaves the box, passes the ray's upper bound U (the exact precise-sphere hit), or
 //    passes the upper bound of a candidate that certainly is a hit (the f32 error bounds can certify most hits).
 //    In the last case the primitives not met are all farther than the exit of the last cell; that distance also
 //    becomes the ray's third bound lo3, so the epilogue would rescan in f64 if the exact result did not beat it
 //    (ray_epilogue) - the stop needs no trust in the certificate.
-// Rays that start farther than 4 E from the scene centre are not walked (the wave scans the lists).
+// Rays that start farther than 256 E from the scene centre are not walked (the wave scans the lists).
 template <int R, int NS, int LISTS>
 __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>& P, int r) {
   const float inf = __builtin_inff();
@@ -574,16 +603,20 @@ __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>&
   const float texit = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fmaxf(az0, az1));
   const float tend = fminf(texit, fmaf(P.U[r], 1.0001f, 1e-4f));
   if (!(t0 <= tend)) return;   // misses the box, or the box lies beyond U
-  // entry cell
-  int cx = (int)floorf((fmaf(dx, t0, ox) - S.g0x) * S.gicx), cy = (int)floorf((fmaf(dy, t0, oy) - S.g0y) * S.gicy),
-      cz = (int)floorf((fmaf(dz, t0, oz) - S.g0z) * S.gicz);
+  // The walk runs from the entry point p = o + t0 d with distances counted from there, so that its rounding scales
+  // with the box and not with how far away the ray started (a bounce off the ground sphere near the horizon).
+  const float px = fmaf(dx, t0, ox), py = fmaf(dy, t0, oy), pz = fmaf(dz, t0, oz);
+  const float tendr = (tend - t0) + fmaf(t0, 1e-6f, 1e-30f);
+  int cx = (int)floorf((px - S.g0x) * S.gicx), cy = (int)floorf((py - S.g0y) * S.gicy), cz = (int)floorf((pz - S.g0z) * S.gicz);
   cx = min(max(cx, 0), S.gnx - 1); cy = min(max(cy, 0), S.gny - 1); cz = min(max(cz, 0), S.gnz - 1);
-  // distance to the next plane of each axis, and between planes (signed like the direction: the step)
-  float tmx = (fmaf((float)(cx + (dx >= 0.0f ? 1 : 0)), S.gcsx, S.g0x) - ox) * ix_;
-  float tmy = (fmaf((float)(cy + (dy >= 0.0f ? 1 : 0)), S.gcsy, S.g0y) - oy) * iy_;
-  float tmz = (fmaf((float)(cz + (dz >= 0.0f ? 1 : 0)), S.gcsz, S.g0z) - oz) * iz_;
+  // distance (from p) to the next plane of each axis, and between planes (signed like the direction: the step)
+  float tmx = (fmaf((float)(cx + (dx >= 0.0f ? 1 : 0)), S.gcsx, S.g0x) - px) * ix_;
+  float tmy = (fmaf((float)(cy + (dy >= 0.0f ? 1 : 0)), S.gcsy, S.g0y) - py) * iy_;
+  float tmz = (fmaf((float)(cz + (dz >= 0.0f ? 1 : 0)), S.gcsz, S.g0z) - pz) * iz_;
   const float sdx = S.gcsx * ix_, sdy = S.gcsy * iy_, sdz = S.gcsz * iz_;
   const int stx = dx >= 0.0f ? 1 : -1, sty = dy >= 0.0f ? 1 : -1, stz = dz >= 0.0f ? 1 : -1;
+  // |2 oc.d - true| <= ~24 eps (|o'| + |c'|): eQ = 64 eps (|o'| + brad)
+  const float eQ = 3.9e-6f * fmaf(__builtin_amdgcn_sqrtf(fmaf(oz, oz, fmaf(oy, oy, ox * ox))), 1.000001f, S.brad);
   int guard = S.gnx + S.gny + S.gnz + 3;
   float hi[NS];        // per scan: smallest upper bound among the candidates that certainly are hits
 #pragma unroll
@@ -593,14 +626,23 @@ __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>&
   while (true) {
     const uint4 cell = cells[(uint32_t)((cz * S.gny + cy) * S.gnx + cx)];
     for (uint32_t e = cell.x, ee = cell.x + cell.y; e < ee; ++e) {
-      const float4 a = S.gridSph[2 * e];
-      // the per-ray cull of scan_sphere, unpacked (same operations in the same order)
+      const float4 a = S.gridSph[e];   // one 16 B load per test: divergent loads are what the walk is bound by
+      // the per-ray cull of scan_sphere, unpacked (same operations in the same order): q = 2 oc.d, pass iff the
+      // LINE meets the sphere.  Two cheap rejects keep lanes out of the (divergent) candidate path:
+      //  * behind: origin certainly outside (c + k4 = 4 (|oc|^2 - r^2) - 4 E + err > 0, the margin E inside thr4
+      //    exceeds err) and certainly moving away (q > eQ): both roots negative;
+      //  * seen: the primitive is already an indexed candidate (it sits in every cell it overlaps).
       float q = fmaf(a.z, dz, PK(P, od2, r)), c = fmaf(a.z, PK(P, o4z, r), PK(P, thr4, r));
       q = fmaf(a.y, dy, q); c = fmaf(a.y, PK(P, o4y, r), c);
       q = fmaf(a.x, dx, q); c = fmaf(a.x, PK(P, o4x, r), c);
-      if (fmaf(q, q, -c) >= a.w) {
-        const float4 b = S.gridSph[2 * e + 1];
+      const bool behind = q > eQ && c + a.w > 0.0f;
+      if (fmaf(q, q, -c) >= a.w && !behind) {
+        const float2 b = S.gridSphX[e];   // (16 r^2, list index)
         const int idx = __float_as_int(b.y);
+        bool seen = true;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) seen = seen && (idx == P.c[k][r].i1 || idx == P.c[k][r].i2);
+        if (seen) continue;
         if (!(LISTS & 1) || idx < S.n_sphF) {
           sphere_candidate<R, NS, true>(S, P, r, a.x, a.y, a.z, b.x, idx, hi);
         } else {
@@ -625,8 +667,9 @@ __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>&
         }
       }
     }
-    const float tn = fminf(tmx, fminf(tmy, tmz));   // exit of this cell
-    if (!(tn <= tend)) break;                       // out of the box or beyond U: nothing left that could win
+    const float tnr = fminf(tmx, fminf(tmy, tmz));   // exit of this cell, from p
+    if (!(tnr <= tendr)) break;                      // out of the box or beyond U: nothing left that could win
+    const float tn = t0 + tnr;
     float best = hi[0];
 #pragma unroll
     for (int k = 1; k < NS; ++k) best = fmaxf(best, hi[k]);
@@ -699,7 +742,33 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P,
   }
   if (grid) {
     // moving triangles are not in the grid; the walk comes last (it may lower lo3 below lo2, which no insert may follow)
-    if (LISTS & 2) scan_mtris<R, NS>(S, P, S.n_sphF + S.n_msph + S.n_triF, 0, 1);
+    // the few primitives too big for the grid (the head of each list): linear, as in the list scan
+    for (int i = 0; i < S.nb_sph; ++i) {
+      const v4f sp = AS_CONST(c_f4p, S.sphF)[i];
+      scan_sphere<R, NS>(S, P, v2f{sp[0], sp[1]}, v2f{sp[2], sp[3]}, AS_CONST(c_f32p, S.sphR2)[i], i);
+    }
+    if (LISTS & 1)
+      for (int i = 0; i < S.nb_msph; ++i) {
+        const v4f sb = AS_CONST(c_f4p, S.msphB)[i];
+        scan_msphere<R, NS>(S, P, v2f{sb[0], sb[1]}, v2f{sb[2], sb[3]}, i);
+      }
+    if (LISTS & 2) {
+      c_f4p tp = AS_CONST(c_f4p, S.triF);
+      for (int s = 0; s < S.nb_tri; ++s) {
+        const v4f a = tp[3 * s], b = tp[3 * s + 1], cc = tp[3 * s + 2];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const float tlo = tri_lower_bound(S, 0.25f * PK(P, o4x, r), 0.25f * PK(P, o4y, r), 0.25f * PK(P, o4z, r), PK(P, dx, r),
+                                            PK(P, dy, r), PK(P, dz, r), mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z),
+                                            mk3(cc.x, cc.y, cc.z), P.U[r]);
+          if (tlo >= 0.0f) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) cand_insert(P.c[k][r], tlo, S.n_sphF + S.n_msph + s);
+          }
+        }
+      }
+      scan_mtris<R, NS>(S, P, S.n_sphF + S.n_msph + S.n_triF, 0, 1);
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r)
       if (PK(P, thr4, r) < __builtin_inff()) grid_walk_ray<R, NS, LISTS>(S, P, r);
@@ -860,7 +929,8 @@ __device__ __forceinline__ void ray_setup(const SceneDev& S, RayPack<R, NS>& P, 
 // After the scan: exact evaluation of the two best candidates, rescan if a third could still win.
 // stats[0] += second evaluations, stats[1] += rescans.
 __device__ __forceinline__ Closest ray_epilogue(const SceneDev& S, float ox, float oy, float oz, float dx, float dy,
-                                                float dz, uint32_t word, const Cand& c, Closest r, uint32_t* stats) {
+                                                float dz, uint32_t word, const Cand& c, Closest r, uint32_t* stats,
+                                                bool* defer = nullptr) {
   d3 o = d3{(double)ox, (double)oy, (double)oz};
   d3 d = d3{(double)dx, (double)dy, (double)dz};
   if (c.i1 >= 0) {
@@ -877,7 +947,9 @@ __device__ __forceinline__ Closest ray_epilogue(const SceneDev& S, float ox, flo
         (r.g < 0 || t < r.t || (t == r.t && S.prim_obj[g] < S.prim_obj[r.g]))) { r.t = t; r.g = g; }
   }
   const bool rescan = c.lo3 < __builtin_inff() && (double)c.lo3 <= r.t;   // lo3 = +inf unless a third candidate exists
-  if (rescan) exact_scan_all(S, o, d, word, &r.t, &r.g);
+  // defer: the caller runs the rescan where the whole wave is convergent (lanes without a ray help too)
+  if (defer) *defer = rescan;
+  else exact_scan_all_wave(S, rescan, o, d, word, &r.t, &r.g);
   if (stats) {
     unsigned long long m2 = __ballot(second), m3 = __ballot(rescan);
     if (m2 | m3) {
@@ -1059,30 +1131,40 @@ __device__ __forceinline__ void isect_park(const RayPack<R, NS>& P, float (*park
 
 // The hit record of slot r (any r: the park is indexed dynamically), scan k, for the ray (o, d) re-read from the
 // queue: (t, prim, px, py), (pz, nx, ny, nz); prim = -1 on a miss.
+// Called by every lane of the wave together (live = this lane has a ray in slot r): the rare f64 rescan in the middle
+// is done by the whole wave for the lanes that need it.
 template <int NS>
-__device__ __forceinline__ void isect_hit(const SceneDev& S, int r, int k, float ox, float oy, float oz, float dx,
-                                          float dy, float dz, float (*park)[CFT_BLOCK], uint32_t* stats, float4* h0,
-                                          float4* h1) {
-  const uint32_t word = __float_as_uint(PARK(r, ParkLayout<NS>::WORD + k));
-  Closest pre;
-  if (k == 0 || !S.prec_motion) {
-    pre.t = __hiloint2double(__float_as_int(PARK(r, 1)), __float_as_int(PARK(r, 0)));
-    pre.g = __float_as_int(PARK(r, 2));
-  } else {
-    pre = precise_hit(S, ox, oy, oz, dx, dy, dz, word);
-  }
-  Cand cd;
-  cd.lo1 = PARK(r, ParkLayout<NS>::CAND + 5 * k + 0);
-  cd.lo2 = PARK(r, ParkLayout<NS>::CAND + 5 * k + 1);
-  cd.lo3 = PARK(r, ParkLayout<NS>::CAND + 5 * k + 2);
-  cd.i1 = __float_as_int(PARK(r, ParkLayout<NS>::CAND + 5 * k + 3));
-  cd.i2 = __float_as_int(PARK(r, ParkLayout<NS>::CAND + 5 * k + 4));
-  Closest c = ray_epilogue(S, ox, oy, oz, dx, dy, dz, word, cd, pre, stats);
+__device__ __forceinline__ void isect_hit(const SceneDev& S, bool live, int r, int k, float ox, float oy, float oz,
+                                          float dx, float dy, float dz, float (*park)[CFT_BLOCK], uint32_t* stats,
+                                          float4* h0, float4* h1) {
   *h0 = make_float4(__builtin_inff(), __int_as_float(-1), 0.f, 0.f);
   *h1 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (c.g >= 0) {
-    d3 o = d3{(double)ox, (double)oy, (double)oz};
-    d3 d = d3{(double)dx, (double)dy, (double)dz};
+  uint32_t word = 0;
+  Closest c;
+  c.t = __builtin_inf();
+  c.g = -1;
+  bool rescan = false;
+  if (live) {
+    word = __float_as_uint(PARK(r, ParkLayout<NS>::WORD + k));
+    Closest pre;
+    if (k == 0 || !S.prec_motion) {
+      pre.t = __hiloint2double(__float_as_int(PARK(r, 1)), __float_as_int(PARK(r, 0)));
+      pre.g = __float_as_int(PARK(r, 2));
+    } else {
+      pre = precise_hit(S, ox, oy, oz, dx, dy, dz, word);
+    }
+    Cand cd;
+    cd.lo1 = PARK(r, ParkLayout<NS>::CAND + 5 * k + 0);
+    cd.lo2 = PARK(r, ParkLayout<NS>::CAND + 5 * k + 1);
+    cd.lo3 = PARK(r, ParkLayout<NS>::CAND + 5 * k + 2);
+    cd.i1 = __float_as_int(PARK(r, ParkLayout<NS>::CAND + 5 * k + 3));
+    cd.i2 = __float_as_int(PARK(r, ParkLayout<NS>::CAND + 5 * k + 4));
+    c = ray_epilogue(S, ox, oy, oz, dx, dy, dz, word, cd, pre, stats, &rescan);
+  }
+  const d3 o = d3{(double)ox, (double)oy, (double)oz};
+  const d3 d = d3{(double)dx, (double)dy, (double)dz};
+  exact_scan_all_wave(S, rescan, o, d, word, &c.t, &c.g);
+  if (live && c.g >= 0) {
     d3 p = o + d * c.t;                        // point = pos + dir * t
     f3 nn = hit_normal(S, c.g, p, word);
     *h0 = make_float4((float)c.t, __int_as_float(c.g), (float)p.x, (float)p.y);
@@ -1116,16 +1198,19 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_intersect(SceneDev S, QueueDev q,
     }
 #pragma unroll 1
     for (int r = 0; r < R; ++r) {
+      if (!(wb + r * stride < n)) break;   // wave-uniform: the whole wave stays together for isect_hit
       const uint32_t i = base + r * stride;
-      if (!(i < n)) break;
-      const float4 a = q.a[i];
-      const float4 b = q.b[i];
+      const bool live = i < n;
+      const float4 a = q.a[live ? i : wb];
+      const float4 b = q.b[live ? i : wb];
 #pragma unroll
       for (int k = 0; k < NS; ++k) {
         float4 h0, h1;
-        isect_hit<NS>(S, r, k, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &h0, &h1);
-        if (k == 0) { out0.h0[i] = h0; out0.h1[i] = h1; }
-        else        { out1.h0[i] = h0; out1.h1[i] = h1; }
+        isect_hit<NS>(S, live, r, k, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &h0, &h1);
+        if (live) {
+          if (k == 0) { out0.h0[i] = h0; out0.h1[i] = h1; }
+          else        { out1.h0[i] = h0; out1.h1[i] = h1; }
+        }
       }
     }
   }
@@ -1425,18 +1510,19 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(SceneDev S, QueueD
     uint32_t alive_bits = 0;
 #pragma unroll 1
     for (int r = 0; r < R; ++r) {
+      if (!(wb + r * stride < n)) break;   // wave-uniform: the whole wave stays together for isect_hit
       const uint32_t i = base + r * stride;
-      if (!(i < n)) break;
-      const float4 a = q.a[i];
-      const float4 b = q.b[i];
-      const float2 c = q.c[i];
+      const bool live = i < n;
+      const float4 a = q.a[live ? i : wb];
+      const float4 b = q.b[live ? i : wb];
+      const float2 c = q.c[live ? i : wb];
       HitInRegisters hit;
-      isect_hit<NS>(S, r, 0, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.a0, &hit.b1);
+      isect_hit<NS>(S, live, r, 0, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.a0, &hit.b1);
       hit.b0 = hit.a0;
-      if (NS == 2) isect_hit<NS>(S, r, 1, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.b0, &hit.b1);
+      if (NS == 2) isect_hit<NS>(S, live, r, 1, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.b0, &hit.b1);
       f3 thr = mk3(b.z, b.w, c.x), npos, ndir;
-      const bool alive = shade_one(S, hit, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), &thr, __float_as_uint(c.y), level,
-                                   max_depth, pid_base, k0, k1, radiance, pq, phong_counts, &npos, &ndir);
+      const bool alive = live && shade_one(S, hit, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), &thr, __float_as_uint(c.y), level,
+                                           max_depth, pid_base, k0, k1, radiance, pq, phong_counts, &npos, &ndir);
       if (alive) {   // the survivor takes over the slot's park words (path id: re-read from the queue below)
         alive_bits |= 1u << r;
         PARK(r, 0) = npos.x; PARK(r, 1) = npos.y; PARK(r, 2) = npos.z; PARK(r, 3) = ndir.x;
@@ -1528,18 +1614,19 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_tail(SceneDev S, QueueDe
     uint32_t alive_bits = 0;
 #pragma unroll 1
     for (int r = 0; r < R; ++r) {
+      if (!(wb + r * stride < n)) break;   // wave-uniform: the whole wave stays together for isect_hit
       const uint32_t i = base + r * stride;
-      if (!(i < n)) break;
-      const float4 a = q.a[i];
-      const float4 b = q.b[i];
-      const float2 c = q.c[i];
+      const bool live = i < n;
+      const float4 a = q.a[live ? i : wb];
+      const float4 b = q.b[live ? i : wb];
+      const float2 c = q.c[live ? i : wb];
       HitInRegisters hit;
-      isect_hit<NS>(S, r, 0, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.a0, &hit.b1);
+      isect_hit<NS>(S, live, r, 0, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.a0, &hit.b1);
       hit.b0 = hit.a0;
-      if (NS == 2) isect_hit<NS>(S, r, 1, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.b0, &hit.b1);
+      if (NS == 2) isect_hit<NS>(S, live, r, 1, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.b0, &hit.b1);
       f3 thr = mk3(b.z, b.w, c.x), npos, ndir;
-      const bool alive = shade_one(S, hit, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), &thr, __float_as_uint(c.y), level,
-                                   max_depth, pid_base, k0, k1, radiance, pq, phong_counts, &npos, &ndir);
+      const bool alive = live && shade_one(S, hit, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), &thr, __float_as_uint(c.y), level,
+                                           max_depth, pid_base, k0, k1, radiance, pq, phong_counts, &npos, &ndir);
       if (alive) {
         alive_bits |= 1u << r;
         PARK(r, 0) = npos.x; PARK(r, 1) = npos.y; PARK(r, 2) = npos.z; PARK(r, 3) = ndir.x;

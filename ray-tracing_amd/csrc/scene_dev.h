@@ -43,9 +43,11 @@ struct SceneDev {
   int n_mtri;
   // ---- uniform grid over the lists above (an extension; 0 cells = none).  Cell (x, y, z) -> gridCell[(z*gny + y)*gnx + x]
   const uint4* gridCell;  // (first sphere entry, count, first triangle entry, count)
-  const float4* gridSph;  // 2 float4 per entry: the sphF / msphB entry, then (16 r^2, list index bits, -, -)
+  const float4* gridSph;  // per entry: the sphF / msphB entry
+  const float2* gridSphX; // per entry: (16 r^2, list index bits), read when the cull passes
   const uint32_t* gridTri;   // index into triF
   int gnx, gny, gnz;
+  int nb_sph, nb_msph, nb_tri;   // the first nb_* entries of sphF / msphF+msphB / triF are too big for the grid: scanned linearly
   int grid_mode;          // 0: lists only; 1: waves too wide for the cone cull walk the grid; 2: every wave does
   float g0x, g0y, g0z, g1x, g1y, g1z;   // the (inflated) box, relative to the scene centre
   float gcsx, gcsy, gcsz, gicx, gicy, gicz;   // cell size and its inverse
