@@ -25,7 +25,7 @@ struct cftrt_ctx {
   int variant = 0;
   int wave_cull = 1;      // level kernels may skip spheres no ray of a wave's bundle can reach (exact either way)
   int grid = 1;           // uniform grid (an extension to the reference's linear scan): 0 off, 1 waves the cone cull does not serve, 2 every wave
-  double grid_density = 4.;   // cells per primitive the grid is sized for (scenes committed afterwards)
+  double grid_density = 1.;   // cells per primitive the grid is sized for (scenes committed afterwards)
   int split = 0;          // 0: fused k_trace_level per level (default); 1: k_intersect -> hit records -> k_shade
   int n_cu = 256;
   // grow-only workspace
@@ -453,7 +453,7 @@ int cftrt_scene_commit(cftrt_scene* s) {
   while (sphF.size() % 4) { sphF.push_back(make_float4(0.f, 0.f, 0.f, 1e30f)); sphR2.push_back(0.f); }   // never hit: 4 disc' = Q^2 - 1e30
   for (int k = 0; k < 4; ++k) { sphF.push_back(make_float4(0.f, 0.f, 0.f, 1e30f)); sphR2.push_back(0.f); }   // the prefetched extra batch
   // Uniform grid over the static spheres, the moving spheres' swept bounds and the static triangles (kernels.h,
-  // grid_walk_ray).  Cubic cells sized for ~4 cells per primitive, at most 128 per axis; every primitive is
+  // grid_walk_ray).  Cubic cells sized for ~1 cell per primitive (measured optimum 0.5 .. 2), at most 128 per axis; every primitive is
   // registered in the cells its bound, inflated by 1e-3 of the box half-extent, overlaps.  Scenes with fewer than 64
   // such primitives, or whose primitives are large against any sensible cell (a Cornell box), get no grid.
   std::vector<uint4> gridCell;

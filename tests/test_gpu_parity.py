@@ -491,7 +491,7 @@ def test_grid_random_scenes(rt, seed, cells):
             dev.set_grid(mode, cells)
             out[mode] = world.render(cam, W, H, depth, seed=seed, return_stats=True)
     finally:
-        dev.set_grid(1, 4.0)
+        dev.set_grid(1, 1.0)
     for mode in (1, 2):
         assert np.array_equal(out[0][0], out[mode][0])
         assert list(out[0][1].rays_per_level[: int(out[0][1].levels)]) == list(out[mode][1].rays_per_level[: int(out[mode][1].levels)])
