@@ -746,6 +746,7 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
                                uint32_t role0, uint32_t role1, QueueDev qout, float4* rad, PhongQueueDev pq,
                                uint32_t* phong_counts, uint32_t* xstats, uint32_t P) {
   int R = ctx->variant ? ctx->variant : CFT_RAYS_PER_LANE;
+  if (!ctx->variant && S.grid_mode) R = 3;   // the instances with the grid walk hold 4 rays only with spills
   if (!ctx->variant && P < (1u << 20)) R = 2;
   if (two_scans && R > 2) R = 2;
   hipStream_t st = ctx->stream;
