@@ -1,0 +1,26 @@
+#!/bin/bash
+# Regenerates the rocprofv3 evidence under profiles/ for the default bench (run on the GPU box from the repo root):
+#   bash scripts/profile_round.sh v4      -> gpurun_out/prof_v4/*  (copy what is to be judged into profiles/)
+# Kernel trace and counters are separate runs; each --pmc pass is its own run within the per-block counter limits.
+set -e
+tag=$1
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+out=gpurun_out/prof_$tag
+mkdir -p $out
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o p -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-plain-scan > $out/bench_under_rocprof.json
+cp $out/stats/p_kernel_stats.csv $out/kernel_stats.csv
+python3 scripts/level_times.py $out/stats > $out/level_times.txt
+CFTRT_GRID=0 CFTRT_WAVE_CULL=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_plain -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-plain-scan > $out/bench_plain_scan_under_rocprof.json
+cp $out/stats_plain/p_kernel_stats.csv $out/kernel_stats_plain_scan.csv
+timeout -k 10 400 python3 bench.py > $out/bench.json
+bash scripts/pmc_pass.sh ${tag}_sq 0 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE
+bash scripts/pmc_pass.sh ${tag}_lds 0 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_LEVEL_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
+bash scripts/pmc_pass.sh ${tag}_tcp 0 TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE
+PMC_WARMUP=1 bash scripts/pmc_pass.sh ${tag}_fetch 0 FETCH_SIZE
+PMC_WARMUP=1 bash scripts/pmc_pass.sh ${tag}_write 0 WRITE_SIZE
+rays=$(python3 -c "import json;print(json.load(open('$out/bench_under_rocprof.json'))['config']['rays_per_step_per_gpu'])")
+python3 scripts/hbm_traffic.py gpurun_out/pmc_${tag}_fetch gpurun_out/pmc_${tag}_write $rays $out/hbm_traffic.json > /dev/null
+cp gpurun_out/pmc_${tag}_sq.json $out/pmc_sq.json
+cp gpurun_out/pmc_${tag}_lds.json $out/pmc_lds_occupancy.json
+cp gpurun_out/pmc_${tag}_tcp.json $out/pmc_ta_tcp.json
+ls -la $out
