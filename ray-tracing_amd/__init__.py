@@ -6,5 +6,5 @@ The directory name carries a hyphen (it is fixed by the build contract), so impo
 from .api import (EPS, Camera, Cube, Device, Dielectric, LambertianModel, LightShape, Metal, Object,  # noqa: F401
                   ParallelLight, PhongModel, PointLight, SkyLight, Specular, Sphere, Square, Transparent,
                   Triangle, World, default_device, vec3_to_rgb)
-from . import multi, scenes  # noqa: F401
+from . import image_io, multi, scenes  # noqa: F401
 from ._lib import CftrtError, LIB_PATH, SYMBOLS, load  # noqa: F401

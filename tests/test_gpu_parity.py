@@ -541,3 +541,25 @@ def test_cpp_examples_match_python_host(rt, tmp_path, name, W, H, spp, depth):
     assert np.abs(img.astype(int) - rt.vec3_to_rgb(want, spp).astype(int)).max() <= 1
     if name == "scene":
         assert "ns/pixel" in out.stdout          # the reference's timing line (scene.rs:105-109)
+
+
+def test_progressive_render_and_png(rt, tmp_path):
+    """The output step (examples/scene.rs:111-119) on a resumable render: two sessions of sample ranges through the
+    accumulation file equal the one-shot render (the per-sample Philox streams are keyed by the sample index; only the
+    f32 order of the chunk sums differs), and the PNG holds the device's 8-bit image."""
+    world, cam = rt.scenes.scene_rs()
+    W, H, depth, spp, seed = 160, 100, 10, 12, 77
+    one = world.render(cam, W, H, depth, seed=seed, spp_begin=0, spp_end=spp)
+    path = str(tmp_path / "acc.npz")
+    rr = lambda b, e: world.render(cam, W, H, depth, seed=seed, spp_begin=b, spp_end=e)
+    kw = dict(width=W, height=H, depth=depth, seed=seed)
+    _, done = rt.image_io.render_progressive(rr, path, spp_total=5, chunk=5, **kw)       # first session
+    assert done == 5
+    acc, done = rt.image_io.render_progressive(rr, path, spp_total=spp, chunk=4, **kw)   # resumed later
+    assert done == spp
+    assert np.allclose(acc, one, rtol=1e-5, atol=1e-5)
+    rgb = rt.vec3_to_rgb(acc, spp)
+    assert np.abs(rgb.astype(int) - rt.image_io.vec3_to_rgb_host(acc, spp).astype(int)).max() <= 1
+    png = str(tmp_path / "test.png")
+    rt.image_io.write_png(png, rgb)
+    assert np.array_equal(rt.image_io.read_png(png), rgb)
