@@ -729,10 +729,12 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P,
     if (!B.live) return;          // no live ray in this wave
     cull = B.narrow;              // wider than ~37 degrees: scan the whole lists
   }
-  // the grid instead of the lists (mode 1: for waves the cone cull does not serve; 2: for every wave), unless a
-  // ray of the wave starts too far out for the walk's error bounds
+  // the grid instead of the lists (mode 1: for waves the cone cull does not serve, and for every wave once the
+  // lists are so long - 4 096 entries - that even one cone test per primitive and wave costs more than the walks;
+  // 2: for every wave), unless a ray of the wave starts too far out for the walk's error bounds
   bool grid = false;
-  if ((LISTS & 4) && nparts == 1 && S.grid_mode && (S.grid_mode == 2 || !cull)) {
+  if ((LISTS & 4) && nparts == 1 && S.grid_mode &&
+      (S.grid_mode == 2 || !cull || S.n_sphF + S.n_msph + S.n_triF > 4096)) {
     bool far = false;
 #pragma unroll
     for (int r = 0; r < R; ++r)
