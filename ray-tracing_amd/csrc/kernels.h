@@ -18,6 +18,11 @@
 // error bounds - and the surviving candidates are re-evaluated in f64 with the reference's own formula,
 // operation for operation, so the reported hit is the primitive and the f64 distance the reference computes
 // for the same ray.  Built with -ffp-contract=off: every FMA in this file is explicit.
+//
+// Which primitives a ray tests: every one of the lists (the reference's linear scan), minus what the wave's cone
+// rules out (scan_spheres_culled), or - an extension, cftrt_ctx_set_grid - those of the grid cells the ray crosses
+// (grid_walk_ray).  All three feed the same candidate sets and the same exact finalisation, so the image does not
+// depend on the choice (tests compare them bit for bit).
 #pragma once
 #include "device_math.h"
 #include "scene_dev.h"
