@@ -1330,11 +1330,23 @@ __device__ __forceinline__ bool shade_one(const SceneDev& S, const H& hit, f3 po
   bool alive = false;
   const float4 A0 = hit.A0();
   const int primA = __float_as_int(A0.y);
+  // the material row is two dependent loads away from the prim id: start them before the lights and HitInfo::new
+  const float4 B0 = hit.B0();
+  const int prim = __float_as_int(B0.y);
+  const MatDev m = S.mats[prim >= 0 ? S.prim_mat[prim] : 0];
   // ---- lights: LightSource::looked (object.rs:333-341)
   bool see = false;
   f3 col = mk3(0, 0, 0);
   for (int l = 0; l < S.n_lights; ++l) {
-    const LightDev L = S.lights[l];
+    LightDev L;   // wave-uniform row: scalar loads
+    {
+      static_assert(sizeof(LightDev) == 44, "LightDev is 11 dwords");
+      c_i32p lp = AS_CONST(c_i32p, S.lights) + 11 * l;
+      int w[11];
+#pragma unroll
+      for (int j = 0; j < 11; ++j) w[j] = lp[j];
+      __builtin_memcpy(&L, w, sizeof L);
+    }
     if (L.kind == 0) {                       // SkyLight::looked, light.rs:184-190
       if (primA < 0) { see = true; col = col + sky_color_from(dir); }
     } else if (L.kind == 1) {                // LightShape::looked, light.rs:233-242
@@ -1347,14 +1359,11 @@ __device__ __forceinline__ bool shade_one(const SceneDev& S, const H& hit, f3 po
   if (see) {
     radiance[lpid] = make_float4(thr.x * col.x, thr.y * col.y, thr.z * col.z, 0.f);
   } else {
-    const float4 B0 = hit.B0();
-    const int prim = __float_as_int(B0.y);
     if (prim < 0) {
       radiance[lpid] = make_float4(0.f, 0.f, 0.f, 0.f);   // object.rs:354
     } else {
       const float4 B1 = hit.B1();
       HitInfoF h = hitinfo_new(mk3(B1.y, B1.z, B1.w), mk3(B0.z, B0.w, B1.x), dir);
-      const MatDev m = S.mats[S.prim_mat[prim]];
       uint64_t pid = pid_base + lpid;
       f3 k = mk3(1, 1, 1);
       bool scattered = true;
@@ -1515,14 +1524,21 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(SceneDev S, QueueD
       isect_park<R, NS>(P, park);
     }
     uint32_t alive_bits = 0;
+    // the slot's ray is re-read from the queue (HBM: the queue is far bigger than the caches); the next slot's
+    // loads are issued before this slot is processed
+    float4 an = q.a[base < n ? base : wb], bn = q.b[base < n ? base : wb];
+    float2 cn = q.c[base < n ? base : wb];
 #pragma unroll 1
     for (int r = 0; r < R; ++r) {
       if (!(wb + r * stride < n)) break;   // wave-uniform: the whole wave stays together for isect_hit
       const uint32_t i = base + r * stride;
       const bool live = i < n;
-      const float4 a = q.a[live ? i : wb];
-      const float4 b = q.b[live ? i : wb];
-      const float2 c = q.c[live ? i : wb];
+      const float4 a = an, b = bn;
+      const float2 c = cn;
+      {
+        const uint32_t inx = i + stride, j = (r + 1 < R && inx < n) ? inx : wb;
+        an = q.a[j]; bn = q.b[j]; cn = q.c[j];
+      }
       HitInRegisters hit;
       isect_hit<NS>(S, live, r, 0, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.a0, &hit.b1);
       hit.b0 = hit.a0;
