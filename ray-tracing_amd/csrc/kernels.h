@@ -1079,14 +1079,15 @@ template <int NS> struct ParkLayout {
 
 // Before the scan: load the lane's R rays of this level (ray i, i + stride, ...), draw the motion words, test the
 // precise spheres, fill the pack.
+// perm (optional): the queue index of each (slot, thread) when the wave has reordered its rays (wave_sort_rays).
 template <int R, int NS>
 __device__ __forceinline__ void isect_setup(const SceneDev& S, const QueueDev& q, uint32_t n, uint32_t base,
                                             uint32_t stride, uint32_t level, uint64_t pid_base, uint32_t k0,
                                             uint32_t k1, uint32_t role0, uint32_t role1, RayPack<R, NS>& P,
-                                            float (*park)[CFT_BLOCK]) {
+                                            float (*park)[CFT_BLOCK], const uint32_t (*perm)[CFT_BLOCK] = nullptr) {
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const uint32_t i = base + r * stride;
+    const uint32_t i = perm ? perm[r][threadIdx.x] : base + r * stride;
     float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 1.f;
     Closest pre;
     pre.t = __builtin_inf(); pre.g = -1;
@@ -1496,6 +1497,73 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_shade(SceneDev S, QueueDev qin, H
 }
 
 // ------------------------------------------------------------------ trace level (fused intersect + shade)
+// Rays of one wave, reordered by how long their grid walk will be.  A wave walks its R slots one after the other
+// and each slot as long as its longest ray, so with random slot membership a wave pays R x the maximum; sorted
+// (slot 0 = the 64 shortest walks ... slot R-1 = the longest) it pays about the 1/R, 2/R ... quantiles.  The key is
+// the number of cells between the ray's entry into the grid's box and its exit (0: misses the box), counted into 32
+// bins in LDS; perm[slot][thread] receives the queue index (0xFFFFFFFF: no ray).  Wave-synchronous: the wave's own
+// LDS rows only, no barrier.  The order of rays inside a wave never affects the image.
+__device__ __forceinline__ uint32_t walk_key(const SceneDev& S, float4 a, float4 b) {
+  const float ox = a.x - S.bcx, oy = a.y - S.bcy, oz = a.z - S.bcz, dx = a.w, dy = b.x, dz = b.y;
+  const float ix_ = __builtin_amdgcn_rcpf(fabsf(dx) < 1e-30f ? copysignf(1e-30f, dx) : dx);
+  const float iy_ = __builtin_amdgcn_rcpf(fabsf(dy) < 1e-30f ? copysignf(1e-30f, dy) : dy);
+  const float iz_ = __builtin_amdgcn_rcpf(fabsf(dz) < 1e-30f ? copysignf(1e-30f, dz) : dz);
+  const float ax0 = (S.g0x - ox) * ix_, ax1 = (S.g1x - ox) * ix_;
+  const float ay0 = (S.g0y - oy) * iy_, ay1 = (S.g1y - oy) * iy_;
+  const float az0 = (S.g0z - oz) * iz_, az1 = (S.g1z - oz) * iz_;
+  const float t0 = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fmaxf(fminf(az0, az1), 0.0f));
+  const float t1 = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fmaxf(az0, az1));
+  if (!(t0 <= t1)) return 0u;
+  const float cells = (t1 - t0) * fmaf(fabsf(dz), S.gicz, fmaf(fabsf(dy), S.gicy, fabsf(dx) * S.gicx));
+  return 1u + (uint32_t)fminf(cells, 30.0f);
+}
+
+template <int R, bool ON> struct SortStore {   // LDS of wave_sort_rays; empty in kernels that do not sort
+  uint32_t perm[R][CFT_BLOCK];   // queue index of (slot, thread)
+  uint32_t hist[CFT_BLOCK / 64][32];
+};
+template <int R> struct SortStore<R, false> {};
+
+template <int R>
+__device__ __forceinline__ void wave_sort_rays(const SceneDev& S, const QueueDev& q, uint32_t n, uint32_t base,
+                                               uint32_t (*perm)[CFT_BLOCK], uint32_t (*hist)[32]) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, col0 = threadIdx.x & ~63u;
+  if (lane < 32u) hist[wave][lane] = 0u;
+#pragma unroll
+  for (int r = 0; r < R; ++r) perm[r][threadIdx.x] = 0xFFFFFFFFu;
+  __builtin_amdgcn_wave_barrier();
+  uint32_t key[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint32_t i = base + r * 64u;
+    key[r] = 32u;
+    if (i < n) {
+      key[r] = walk_key(S, q.a[i], q.b[i]);
+      atomicAdd(&hist[wave][key[r]], 1u);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  {   // exclusive prefix over the 32 bins (lanes 0..31)
+    const uint32_t h = lane < 32u ? hist[wave][lane] : 0u;
+    uint32_t incl = h;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+      const uint32_t t = __shfl_up(incl, o);
+      if (lane >= (uint32_t)o) incl += t;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 32u) hist[wave][lane] = incl - h;
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (key[r] < 32u) {
+      const uint32_t p = atomicAdd(&hist[wave][key[r]], 1u);   // the ray's rank: bins ascending, arrival order inside
+      perm[p >> 6][col0 + (p & 63u)] = base + r * 64u;
+    }
+  __builtin_amdgcn_wave_barrier();
+}
+
 // The default pipeline.  One launch per trace level: the intersect stage above, then World::trace's shading of
 // each ray straight from registers, then the survivors are appended to the next level's queue.  Against the
 // split pipeline this removes the hit records (32 B written + read per ray and scan) and the second read of
@@ -1511,32 +1579,53 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(SceneDev S, QueueD
                                                            float4* radiance, PhongQueueDev pq, uint32_t* phong_counts,
                                                            uint32_t* stats) {
   __shared__ float park[ParkLayout<NS>::WORDS * R][CFT_BLOCK];
+  // (the 4-ray instances serve the primary rays, which are not sorted; their park already fills the 40 KB a block
+  // may take at 4 blocks per CU)
+  constexpr bool SORT = (LISTS & 4) != 0 && R < 4 && NS == 1;   // (two-scan instances: measured slower, they spill)
+  __shared__ SortStore<R, SORT> ss;
   const uint32_t n = counts[level];
   const uint32_t stride = 64u;   // wave-contiguous slots, wave-uniform trip count (see k_intersect)
   const uint32_t wstep = gridDim.x * CFT_BLOCK * R;
   const uint32_t lane = threadIdx.x & 63u;
+  // bounce rays that will walk the grid are sorted by walk length inside the wave (primary rays take the cone cull)
+  const bool sorted = SORT && S.grid_mode && level > 0;
+  auto slot_index = [&](int r, uint32_t base) -> uint32_t {
+    if constexpr (SORT) return ss.perm[r][threadIdx.x];
+    else return base + r * 64u < n ? base + r * 64u : 0xFFFFFFFFu;
+  };
   for (uint32_t wb = (blockIdx.x * CFT_BLOCK + (threadIdx.x & ~63u)) * R; wb < n; wb += wstep) {
     const uint32_t base = wb + lane;
+    if constexpr (SORT) {
+      if (sorted) {
+        wave_sort_rays<R>(S, q, n, base, ss.perm, ss.hist);
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) ss.perm[r][threadIdx.x] = base + r * stride < n ? base + r * stride : 0xFFFFFFFFu;
+      }
+    }
     {
       RayPack<R, NS> P;
-      isect_setup<R, NS>(S, q, n, base, stride, level, pid_base, k0, k1, role0, role1, P, park);
+      if constexpr (SORT) isect_setup<R, NS>(S, q, n, base, stride, level, pid_base, k0, k1, role0, role1, P, park, ss.perm);
+      else isect_setup<R, NS>(S, q, n, base, stride, level, pid_base, k0, k1, role0, role1, P, park);
       scan_lists<R, NS, true, LISTS>(S, P);
       isect_park<R, NS>(P, park);
     }
     uint32_t alive_bits = 0;
     // the slot's ray is re-read from the queue (HBM: the queue is far bigger than the caches); the next slot's
     // loads are issued before this slot is processed
-    float4 an = q.a[base < n ? base : wb], bn = q.b[base < n ? base : wb];
-    float2 cn = q.c[base < n ? base : wb];
+    uint32_t inext = slot_index(0, base);
+    float4 an = q.a[inext < n ? inext : wb], bn = q.b[inext < n ? inext : wb];
+    float2 cn = q.c[inext < n ? inext : wb];
 #pragma unroll 1
     for (int r = 0; r < R; ++r) {
       if (!(wb + r * stride < n)) break;   // wave-uniform: the whole wave stays together for isect_hit
-      const uint32_t i = base + r * stride;
+      const uint32_t i = inext;
       const bool live = i < n;
       const float4 a = an, b = bn;
       const float2 c = cn;
       {
-        const uint32_t inx = i + stride, j = (r + 1 < R && inx < n) ? inx : wb;
+        inext = r + 1 < R ? slot_index(r + 1, base) : 0xFFFFFFFFu;
+        const uint32_t j = inext < n ? inext : wb;
         an = q.a[j]; bn = q.b[j]; cn = q.c[j];
       }
       HitInRegisters hit;
@@ -1569,7 +1658,7 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(SceneDev S, QueueD
           const uint32_t o = wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
           qout.a[o] = make_float4(PARK(r, 0), PARK(r, 1), PARK(r, 2), PARK(r, 3));
           qout.b[o] = make_float4(PARK(r, 4), PARK(r, 5), PARK(r, 6), PARK(r, 7));
-          qout.c[o] = make_float2(PARK(r, 8), q.c[base + r * stride].y);
+          qout.c[o] = make_float2(PARK(r, 8), q.c[slot_index(r, base)].y);
         }
         wbase += (uint32_t)__popcll(m);
       }
