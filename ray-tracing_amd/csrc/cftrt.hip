@@ -754,7 +754,8 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
   hipStream_t st = ctx->stream;
   // static spheres only (S500 and the like): kernels compiled without the moving-sphere and triangle lists
   const bool lean = !S.n_msph && !S.n_triF && !S.n_mtri;
-  const uint32_t tail_below = 1u << 19;   // measured optimum on S500 (2^18 .. 2^20 within 1 %)
+  // measured on S500: 2^18 .. 2^20 within 1 % on the lists; with the grid the level kernel stays ahead down to ~2^17
+  const uint32_t tail_below = S.grid_mode ? 1u << 17 : 1u << 19;
   // (with the grid no wave scans a whole list; short lists are still quicker split over the four waves)
   if (!ctx->variant && P < tail_below && (!S.grid_mode || S.n_sphF + S.n_msph + S.n_triF <= 2048)) {
     // too few rays to fill the chip: the list is split over the 4 waves of a block (k_trace_tail), 128 rays per block
@@ -785,8 +786,11 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
     }                                                                     \
   }
   // instances: with / without the moving-sphere and triangle lists, with / without the grid walk
-  if (S.grid_mode) { if (lean) { CFT_LAUNCH_R(4) } else { CFT_LAUNCH_R(7) } }
-  else             { if (lean) { CFT_LAUNCH_R(0) } else { CFT_LAUNCH_R(3) } }
+  // (primary rays of a scene whose lists are short take the cone cull, or at worst the lists: the instance without
+  // the walk has the registers for 4 rays per lane without spills)
+  const bool walk = S.grid_mode && (level > 0 || S.grid_mode == 2 || S.n_sphF + S.n_msph + S.n_triF > 4096);
+  if (walk) { if (lean) { CFT_LAUNCH_R(4) } else { CFT_LAUNCH_R(7) } }
+  else      { if (lean) { CFT_LAUNCH_R(0) } else { CFT_LAUNCH_R(3) } }
 #undef CFT_LAUNCH_R
 #undef CFT_LAUNCH
 }
