@@ -563,3 +563,61 @@ def test_progressive_render_and_png(rt, tmp_path):
     png = str(tmp_path / "test.png")
     rt.image_io.write_png(png, rgb)
     assert np.array_equal(rt.image_io.read_png(png), rgb)
+
+
+def test_grid_triangles_only_and_degenerate_boxes(rt, orc):
+    """Grid corner cases: a world without any sphere (the sphere entry array is empty), two huge triangles that stay
+    out of the grid as the lists' linear prefix, and 80 tiny spheres on one plane z = const (a box of zero height
+    before its margin).  Lists and grid agree bit for bit, and the parity hook (which walks the grid) agrees with the
+    oracle on ids and distances."""
+    rng = np.random.default_rng(77)
+    A = rt
+    mats = [A.LambertianModel(0.9).with_color((0.7, 0.7, 0.7)), A.Metal(0.1, 0.9), A.Dielectric(1.5)]
+    dev = rt.default_device()
+
+    def tri_world():
+        w = A.World.empty()
+        w.add_obj(A.Object(A.Triangle((-40.0, -40.0, 0.0), (40.0, -40.0, 0.0), (0.0, 60.0, 0.0)), mats[0]))   # floor
+        w.add_obj(A.Object(A.Triangle((-40.0, 30.0, 0.0), (40.0, 30.0, 0.0), (0.0, 30.0, 50.0)), mats[1]))    # back wall
+        for i in range(120):
+            p = rng.uniform(-6, 6, 3); p[2] = abs(p[2]) * 0.5 + 0.05
+            w.add_obj(A.Object(A.Triangle(tuple(p), tuple(p + rng.uniform(-0.6, 0.6, 3)), tuple(p + rng.uniform(-0.6, 0.6, 3))),
+                               mats[i % 3]))
+        w.add_light(A.SkyLight())
+        return w
+
+    def flat_world():
+        w = A.World.empty()
+        w.add_obj(A.Object(A.Sphere((0.0, 0.0, -500.0), 500.0), mats[0]))
+        for i in range(80):
+            w.add_obj(A.Object(A.Sphere((float(rng.uniform(-5, 5)), float(rng.uniform(-5, 5)), 0.3), 0.05), mats[i % 3]))
+        w.add_light(A.SkyLight())
+        return w
+
+    cam = (A.Camera.new((9.0, -7.0, 3.0), (0.0, 0.0, 0.3)).with_fov(40.0).with_aspect(2.0).with_sample_rate(4))
+    W, H, depth = 192, 96, 8
+    for make in (tri_world, flat_world):
+        state = rng.bit_generator.state
+        out = {}
+        try:
+            for mode in (0, 1, 2):
+                rng.bit_generator.state = state          # the same world for every mode (a fresh commit each)
+                world = make()
+                dev.set_grid(mode)
+                out[mode] = world.render(cam, W, H, depth, seed=5, return_stats=True)
+        finally:
+            dev.set_grid(1)
+        for mode in (1, 2):
+            assert np.array_equal(out[0][0], out[mode][0])
+            assert list(out[0][1].rays_per_level[:depth]) == list(out[mode][1].rays_per_level[:depth])
+        assert int(out[0][1].rays) > W * H * 4
+        # the hook against the oracle on incoherent rays from inside the scene
+        n = 4000
+        o = np.column_stack([rng.uniform(-5, 5, n), rng.uniform(-5, 5, n), rng.uniform(0.05, 2.0, n)])
+        d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        rays = np.hstack([o, d]).astype(np.float32)
+        ids, t, _, _ = world.intersect(rays)
+        oid, ot = orc.OracleWorld(world).hit(rays.astype(np.float64))[:2]
+        assert np.array_equal(ids, oid)
+        hit = oid >= 0
+        assert np.array_equal(t[hit], ot[hit])
