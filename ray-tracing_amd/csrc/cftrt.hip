@@ -748,7 +748,7 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
   int R = ctx->variant ? ctx->variant : CFT_RAYS_PER_LANE;
   // the instances with the grid walk hold 4 rays only with spills: 3, except for the primary rays, whose narrow
   // bundles take the cone cull (4 rays share each sphere's scalar loads) and never walk
-  if (!ctx->variant && S.grid_mode && level > 0) R = 3;
+  if (!ctx->variant && S.grid_mode && (level > 0 || S.grid_mode == 2)) R = 3;
   if (!ctx->variant && P < (1u << 20)) R = 2;
   if (two_scans && R > 2) R = 2;
   hipStream_t st = ctx->stream;
@@ -788,7 +788,7 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
   // instances: with / without the moving-sphere and triangle lists, with / without the grid walk
   // (primary rays of a scene whose lists are short take the cone cull, or at worst the lists: the instance without
   // the walk has the registers for 4 rays per lane without spills)
-  const bool walk = S.grid_mode && (level > 0 || S.grid_mode == 2 || S.n_sphF + S.n_msph + S.n_triF > 4096);
+  const bool walk = S.grid_mode && (level > 0 || S.grid_mode == 2);
   if (walk) { if (lean) { CFT_LAUNCH_R(4) } else { CFT_LAUNCH_R(7) } }
   else      { if (lean) { CFT_LAUNCH_R(0) } else { CFT_LAUNCH_R(3) } }
 #undef CFT_LAUNCH_R
@@ -851,6 +851,7 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
   SceneDev S = s->dev;
   S.wave_cull = ctx->wave_cull;
   S.grid_mode = S.gnx ? ctx->grid : 0;
+  if (S.grid_mode == 1 && S.n_sphF + S.n_msph + S.n_triF > 4096) S.grid_mode = 2;   // long lists: every wave walks
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
   const bool phong = S.n_phong_mats > 0;
   const bool two_scans = S.any_motion && S.n_lights > 0;   // `looked` and trace each draw their own motion times

@@ -734,12 +734,12 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P,
     if (!B.live) return;          // no live ray in this wave
     cull = B.narrow;              // wider than ~37 degrees: scan the whole lists
   }
-  // the grid instead of the lists (mode 1: for waves the cone cull does not serve, and for every wave once the
-  // lists are so long - 4 096 entries - that even one cone test per primitive and wave costs more than the walks;
-  // 2: for every wave), unless a ray of the wave starts too far out for the walk's error bounds
+  // the grid instead of the lists (mode 1: for waves the cone cull does not serve; 2: for every wave - also what the
+  // host makes of mode 1 once the lists are so long, 4 096 entries, that even one cone test per primitive and wave
+  // costs more than the walks), unless a ray of the wave starts too far out for the walk's error bounds
   bool grid = false;
   if ((LISTS & 4) && nparts == 1 && S.grid_mode &&
-      (S.grid_mode == 2 || !cull || S.n_sphF + S.n_msph + S.n_triF > 4096)) {
+      (S.grid_mode == 2 || !cull)) {
     bool far = false;
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -1588,7 +1588,7 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(SceneDev S, QueueD
   const uint32_t wstep = gridDim.x * CFT_BLOCK * R;
   const uint32_t lane = threadIdx.x & 63u;
   // bounce rays that will walk the grid are sorted by walk length inside the wave (primary rays take the cone cull)
-  const bool sorted = SORT && S.grid_mode && level > 0;
+  const bool sorted = SORT && S.grid_mode && (level > 0 || S.grid_mode == 2);
   auto slot_index = [&](int r, uint32_t base) -> uint32_t {
     if constexpr (SORT) return ss.perm[r][threadIdx.x];
     else return base + r * 64u < n ? base + r * 64u : 0xFFFFFFFFu;
