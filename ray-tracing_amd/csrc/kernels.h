@@ -905,9 +905,21 @@ __device__ __forceinline__ Closest precise_hit(const SceneDev& S, float ox, floa
   r.t = __builtin_inf();
   r.g = -1;
   for (int k = 0; k < S.n_prec; ++k) {
-    int g = AS_CONST(c_i32p, S.prec_gid)[k];
+    // g is wave-uniform: the sphere comes through scalar loads (precise primitives are spheres: g < n_sph)
+    const int g = AS_CONST(c_i32p, S.prec_gid)[k];
+    c_f64p sp = AS_CONST(c_f64p, S.sphD) + 4 * (size_t)g;
+    d3 c = d3{sp[0], sp[1], sp[2]};
+    const double rad = sp[3];
+    if (S.prec_motion) {
+      c_f64p mp = AS_CONST(c_f64p, S.sphMvD) + 3 * (size_t)g;
+      const d3 mv = d3{mp[0], mp[1], mp[2]};
+      if (mv.x != 0. || mv.y != 0. || mv.z != 0.) {
+        const double tm = (double)motion_time(word, (uint32_t)AS_CONST(c_i32p, S.prim_obj)[g]);
+        c = c + mv * tm;
+      }
+    }
     double t;
-    if (exact_prim(S, g, o, d, word, &t)) {
+    if (exact_sphere(o, d, c, rad, &t)) {
       if (t < r.t || (t == r.t && S.prim_obj[g] < S.prim_obj[r.g])) { r.t = t; r.g = g; }
     }
   }
