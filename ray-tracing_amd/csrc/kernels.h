@@ -629,7 +629,7 @@ __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>&
   float tstop = inf;   // lower bound on the distance of every primitive the walk did not meet
   const uint4* cells = S.gridCell;
   while (true) {
-    const uint4 cell = cells[(uint32_t)((cz * S.gny + cy) * S.gnx + cx)];
+    const uint4 cell = cells[__umul24(__umul24((uint32_t)cz, (uint32_t)S.gny) + (uint32_t)cy, (uint32_t)S.gnx) + (uint32_t)cx];   // < 2^21
     for (uint32_t e = cell.x, ee = cell.x + cell.y; e < ee; ++e) {
       const float4 a = S.gridSph[e];   // one 16 B load per test: divergent loads are what the walk is bound by
       // the per-ray cull of scan_sphere, unpacked (same operations in the same order): q = 2 oc.d, pass iff the
@@ -1007,10 +1007,10 @@ struct CamDev {   // viewport constants of Camera::emit_rays (ray.rs:112-118), c
   uint32_t width, height;
 };
 
+// pix = pid mod (width * height) when the caller knows it (k_generate's tiled order), 0xFFFFFFFF otherwise.
 __device__ __forceinline__ void primary_ray(const CamDev& C, uint64_t pid, uint32_t k0, uint32_t k1, int jitter,
-                                            f3* pos, f3* dir) {
-  uint64_t npix = (uint64_t)C.width * C.height;
-  uint32_t pix = (uint32_t)(pid % npix);
+                                            f3* pos, f3* dir, uint32_t pix = 0xFFFFFFFFu) {
+  if (pix == 0xFFFFFFFFu) pix = (uint32_t)(pid % ((uint64_t)C.width * C.height));   // (a 64-bit division)
   uint32_t w = pix % C.width, h = pix / C.width;   // image index h*WIDTH + w (scene.rs:97)
   float urw = 0.5f, urh = 0.5f, uth = 0.0f, ur = 0.0f;
   if (jitter) {
@@ -1038,15 +1038,16 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_generate(CamDev C, uint64_t pid_b
                                                         uint32_t k1, int jitter, int tiled, QueueDev q) {
   const uint32_t npix = C.width * C.height;
   for (uint32_t i = blockIdx.x * CFT_BLOCK + threadIdx.x; i < n; i += gridDim.x * CFT_BLOCK) {
-    uint32_t lp = i;
-    if (tiled) {
+    uint32_t lp = i, pix = 0xFFFFFFFFu;
+    if (tiled) {   // (pid_base is a multiple of npix here, so the pixel of path pid_base + lp is lp mod npix)
       const uint32_t smp = i / npix, j = i - smp * npix;
       const uint32_t t = j >> 8, wi = j & 255u, ntx = C.width >> 5;
       const uint32_t ty = t / ntx, tx = t - ty * ntx;
-      lp = smp * npix + (ty * 8u + (wi >> 5)) * C.width + tx * 32u + (wi & 31u);
+      pix = (ty * 8u + (wi >> 5)) * C.width + tx * 32u + (wi & 31u);
+      lp = smp * npix + pix;
     }
     f3 pos, dir;
-    primary_ray(C, pid_base + lp, k0, k1, jitter, &pos, &dir);
+    primary_ray(C, pid_base + lp, k0, k1, jitter, &pos, &dir, pix);
     q.a[i] = make_float4(pos.x, pos.y, pos.z, dir.x);
     q.b[i] = make_float4(dir.y, dir.z, 1.0f, 1.0f);
     q.c[i] = make_float2(1.0f, __uint_as_float(lp));
