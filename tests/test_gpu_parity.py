@@ -621,3 +621,10 @@ def test_grid_triangles_only_and_degenerate_boxes(rt, orc):
         assert np.array_equal(ids, oid)
         hit = oid >= 0
         assert np.array_equal(t[hit], ot[hit])
+
+
+def test_set_grid_rejects_bad_mode(rt):
+    dev = rt.default_device()
+    with pytest.raises(rt.CftrtError):
+        dev.set_grid(3)
+    dev.set_grid(1)
