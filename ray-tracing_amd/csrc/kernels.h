@@ -1620,9 +1620,9 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(SceneDev S, QueueD
       RayPack<R, NS> P;
       if constexpr (SORT) isect_setup<R, NS>(S, q, n, base, stride, level, pid_base, k0, k1, role0, role1, P, park, ss.perm);
       else isect_setup<R, NS>(S, q, n, base, stride, level, pid_base, k0, k1, role0, role1, P, park);
-      // (the sorting instances run the bounce levels, where nearly every wave walks the grid: without the cone-cull
-      // code they keep more registers; the few narrow bundles there walk too)
-      scan_lists<R, NS, !SORT, LISTS>(S, P);
+      // (the instances with the walk run the bounce levels, where nearly every wave walks the grid: without the
+      // cone-cull code they keep more registers; the few narrow bundles there walk too)
+      scan_lists<R, NS, (LISTS & 4) == 0, LISTS>(S, P);
       isect_park<R, NS>(P, park);
     }
     uint32_t alive_bits = 0;
