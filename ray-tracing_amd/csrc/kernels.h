@@ -737,8 +737,11 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P,
   // the grid instead of the lists (mode 1: for waves the cone cull does not serve; 2: for every wave - also what the
   // host makes of mode 1 once the lists are so long, 4 096 entries, that even one cone test per primitive and wave
   // costs more than the walks), unless a ray of the wave starts too far out for the walk's error bounds
-  bool grid = false;
-  if ((LISTS & 4) && nparts == 1 && S.grid_mode &&
+  // LISTS & 8: the caller guarantees a grid and sends every wave through it (the level kernels' walk instances);
+  // a ray that starts too far out is then not walked but handed to the exact f64 rescan (lo3 = 0), and the
+  // instance carries no list-scan code at all.
+  bool grid = (LISTS & 8) != 0;
+  if (!(LISTS & 8) && (LISTS & 4) && nparts == 1 && S.grid_mode &&
       (S.grid_mode == 2 || !cull)) {
     bool far = false;
 #pragma unroll
@@ -778,9 +781,17 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P,
     }
 #pragma unroll
     for (int r = 0; r < R; ++r)
-      if (PK(P, thr4, r) < __builtin_inff()) grid_walk_ray<R, NS, LISTS>(S, P, r);
+      if (PK(P, thr4, r) < __builtin_inff()) {
+        if ((LISTS & 8) && fmaxf(fabsf(PK(P, o4x, r)), fmaxf(fabsf(PK(P, o4y, r)), fabsf(PK(P, o4z, r)))) > S.gfar4) {
+#pragma unroll
+          for (int k = 0; k < NS; ++k) P.c[k][r].lo3 = 0.0f;   // too far out for the walk's error bounds: rescan
+        } else {
+          grid_walk_ray<R, NS, LISTS>(S, P, r);
+        }
+      }
     return;
   }
+  if (LISTS & 8) return;   // (not reached)
   if (cull) {
     scan_spheres_culled<R, NS>(S, P, B, lo4 << 2, min(hi4 << 2, S.n_sphF));
   } else {
@@ -1622,7 +1633,7 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(SceneDev S, QueueD
       else isect_setup<R, NS>(S, q, n, base, stride, level, pid_base, k0, k1, role0, role1, P, park);
       // (the instances with the walk run the bounce levels, where nearly every wave walks the grid: without the
       // cone-cull code they keep more registers; the few narrow bundles there walk too)
-      scan_lists<R, NS, (LISTS & 4) == 0, LISTS>(S, P);
+      scan_lists<R, NS, (LISTS & 4) == 0, (LISTS & 4) ? (LISTS | 8) : LISTS>(S, P);
       isect_park<R, NS>(P, park);
     }
     uint32_t alive_bits = 0;
