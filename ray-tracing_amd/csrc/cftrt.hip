@@ -746,9 +746,6 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
                                uint32_t role0, uint32_t role1, QueueDev qout, float4* rad, PhongQueueDev pq,
                                uint32_t* phong_counts, uint32_t* xstats, uint32_t P) {
   int R = ctx->variant ? ctx->variant : CFT_RAYS_PER_LANE;
-  // the instances with the grid walk hold 4 rays only with spills: 3, except for the primary rays, whose narrow
-  // bundles take the cone cull (4 rays share each sphere's scalar loads) and never walk
-  if (!ctx->variant && S.grid_mode && (level > 0 || S.grid_mode == 2)) R = 3;
   if (!ctx->variant && P < (1u << 20)) R = 2;
   if (two_scans && R > 2) R = 2;
   hipStream_t st = ctx->stream;

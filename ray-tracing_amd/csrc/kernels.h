@@ -1108,10 +1108,11 @@ template <int R, int NS>
 __device__ __forceinline__ void isect_setup(const SceneDev& S, const QueueDev& q, uint32_t n, uint32_t base,
                                             uint32_t stride, uint32_t level, uint64_t pid_base, uint32_t k0,
                                             uint32_t k1, uint32_t role0, uint32_t role1, RayPack<R, NS>& P,
-                                            float (*park)[CFT_BLOCK], const uint32_t (*perm)[CFT_BLOCK] = nullptr) {
+                                            float (*park)[CFT_BLOCK], const uint16_t (*perm)[CFT_BLOCK] = nullptr) {
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const uint32_t i = perm ? perm[r][threadIdx.x] : base + r * stride;
+    // (with perm, base is the wave's first ray)
+    const uint32_t i = perm ? (perm[r][threadIdx.x] == 0xFFFFu ? 0xFFFFFFFFu : base + perm[r][threadIdx.x]) : base + r * stride;
     float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 1.f;
     Closest pre;
     pre.t = __builtin_inf(); pre.g = -1;
@@ -1543,18 +1544,18 @@ __device__ __forceinline__ uint32_t walk_key(const SceneDev& S, float4 a, float4
 }
 
 template <int R, bool ON> struct SortStore {   // LDS of wave_sort_rays; empty in kernels that do not sort
-  uint32_t perm[R][CFT_BLOCK];   // queue index of (slot, thread)
+  uint16_t perm[R][CFT_BLOCK];   // queue index of (slot, thread) as an offset from the wave's first ray; 0xFFFF: none
   uint32_t hist[CFT_BLOCK / 64][32];
 };
 template <int R> struct SortStore<R, false> {};
 
 template <int R>
 __device__ __forceinline__ void wave_sort_rays(const SceneDev& S, const QueueDev& q, uint32_t n, uint32_t base,
-                                               uint32_t (*perm)[CFT_BLOCK], uint32_t (*hist)[32]) {
+                                               uint16_t (*perm)[CFT_BLOCK], uint32_t (*hist)[32]) {
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, col0 = threadIdx.x & ~63u;
   if (lane < 32u) hist[wave][lane] = 0u;
 #pragma unroll
-  for (int r = 0; r < R; ++r) perm[r][threadIdx.x] = 0xFFFFFFFFu;
+  for (int r = 0; r < R; ++r) perm[r][threadIdx.x] = (uint16_t)0xFFFFu;
   __builtin_amdgcn_wave_barrier();
   uint32_t key[R];
 #pragma unroll
@@ -1583,7 +1584,7 @@ __device__ __forceinline__ void wave_sort_rays(const SceneDev& S, const QueueDev
   for (int r = 0; r < R; ++r)
     if (key[r] < 32u) {
       const uint32_t p = atomicAdd(&hist[wave][key[r]], 1u);   // the ray's rank: bins ascending, arrival order inside
-      perm[p >> 6][col0 + (p & 63u)] = base + r * 64u;
+      perm[p >> 6][col0 + (p & 63u)] = (uint16_t)(lane + r * 64u);
     }
   __builtin_amdgcn_wave_barrier();
 }
@@ -1605,7 +1606,7 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(SceneDev S, QueueD
   __shared__ float park[ParkLayout<NS>::WORDS * R][CFT_BLOCK];
   // (the 4-ray instances serve the primary rays, which are not sorted; their park already fills the 40 KB a block
   // may take at 4 blocks per CU)
-  constexpr bool SORT = (LISTS & 4) != 0 && R < 4 && NS == 1;   // (two-scan instances: measured slower, they spill)
+  constexpr bool SORT = (LISTS & 4) != 0 && NS == 1;   // (two-scan instances: measured slower, they spill)
   __shared__ SortStore<R, SORT> ss;
   const uint32_t n = counts[level];
   const uint32_t stride = 64u;   // wave-contiguous slots, wave-uniform trip count (see k_intersect)
@@ -1614,7 +1615,7 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(SceneDev S, QueueD
   // bounce rays that will walk the grid are sorted by walk length inside the wave (primary rays take the cone cull)
   const bool sorted = SORT && S.grid_mode && (level > 0 || S.grid_mode == 2);
   auto slot_index = [&](int r, uint32_t base) -> uint32_t {
-    if constexpr (SORT) return ss.perm[r][threadIdx.x];
+    if constexpr (SORT) return ss.perm[r][threadIdx.x] == 0xFFFFu ? 0xFFFFFFFFu : base - (threadIdx.x & 63u) + ss.perm[r][threadIdx.x];
     else return base + r * 64u < n ? base + r * 64u : 0xFFFFFFFFu;
   };
   for (uint32_t wb = (blockIdx.x * CFT_BLOCK + (threadIdx.x & ~63u)) * R; wb < n; wb += wstep) {
@@ -1624,12 +1625,12 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(SceneDev S, QueueD
         wave_sort_rays<R>(S, q, n, base, ss.perm, ss.hist);
       } else {
 #pragma unroll
-        for (int r = 0; r < R; ++r) ss.perm[r][threadIdx.x] = base + r * stride < n ? base + r * stride : 0xFFFFFFFFu;
+        for (int r = 0; r < R; ++r) ss.perm[r][threadIdx.x] = base + r * stride < n ? (uint16_t)(lane + r * stride) : (uint16_t)0xFFFFu;
       }
     }
     {
       RayPack<R, NS> P;
-      if constexpr (SORT) isect_setup<R, NS>(S, q, n, base, stride, level, pid_base, k0, k1, role0, role1, P, park, ss.perm);
+      if constexpr (SORT) isect_setup<R, NS>(S, q, n, wb, stride, level, pid_base, k0, k1, role0, role1, P, park, ss.perm);
       else isect_setup<R, NS>(S, q, n, base, stride, level, pid_base, k0, k1, role0, role1, P, park);
       // (the instances with the walk run the bounce levels, where nearly every wave walks the grid: without the
       // cone-cull code they keep more registers; the few narrow bundles there walk too)
