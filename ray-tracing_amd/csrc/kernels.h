@@ -590,7 +590,8 @@ __device__ __forceinline__ void scan_msphere(const SceneDev& S, RayPack<R, NS>& 
 //    In the last case the primitives not met are all farther than the exit of the last cell; that distance also
 //    becomes the ray's third bound lo3, so the epilogue would rescan in f64 if the exact result did not beat it
 //    (ray_epilogue) - the stop needs no trust in the certificate.
-// Rays that start farther than 256 E from the scene centre are not walked (the wave scans the lists).
+// Rays that start farther than 256 E from the scene centre are not walked: in the level kernels they go to the exact
+// f64 rescan (lo3 = 0), in the one-ray form closest_hit the wave scans the lists.
 template <int R, int NS, int LISTS>
 __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>& P, int r) {
   const float inf = __builtin_inff();
