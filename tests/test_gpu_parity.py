@@ -483,7 +483,7 @@ def test_grid_random_scenes(rt, seed, cells):
     """Random worlds with moving spheres (registered by their swept bounds) and triangles, at three grid
     resolutions (a fresh commit each: the resolution is fixed at commit): lists and grid agree bit for bit."""
     dev = rt.default_device()
-    W, H, depth = 256, 128, 12
+    W, H, depth = 512, 256, 12   # > 2^17 rays per bounce level: the level kernels walk (the tail kernel scans lists)
     out = {}
     try:
         for mode in (0, 1, 2):
@@ -595,7 +595,7 @@ def test_grid_triangles_only_and_degenerate_boxes(rt, orc):
         return w
 
     cam = (A.Camera.new((9.0, -7.0, 3.0), (0.0, 0.0, 0.3)).with_fov(40.0).with_aspect(2.0).with_sample_rate(4))
-    W, H, depth = 192, 96, 8
+    W, H, depth = 512, 256, 8
     for make in (tri_world, flat_world):
         state = rng.bit_generator.state
         out = {}
@@ -628,3 +628,37 @@ def test_set_grid_rejects_bad_mode(rt):
     with pytest.raises(rt.CftrtError):
         dev.set_grid(3)
     dev.set_grid(1)
+
+
+def test_grid_far_origins_go_to_the_rescan(rt):
+    """Bounce rays that start more than 256 box-extents from the scene centre (here: off a huge ground sphere, far
+    from a 10 cm cluster of 100 spheres) are not walked through the grid but resolved by the exact f64 rescan.
+    The image must not change, and the rescan counter shows that the path was taken."""
+    rng = np.random.default_rng(3)
+    A = rt
+    dev = rt.default_device()
+
+    def make():
+        w = A.World.empty()
+        w.add_obj(A.Object(A.Sphere((0.0, 0.0, -2000.0), 2000.0), A.LambertianModel(0.8).with_color((0.6, 0.6, 0.6))))
+        g = np.random.default_rng(11)
+        for i in range(100):
+            c = (float(g.uniform(-0.05, 0.05)), float(g.uniform(-0.05, 0.05)), float(g.uniform(0.01, 0.08)))
+            m = A.Metal(0.0, 0.9) if i % 3 == 0 else A.LambertianModel(0.9).with_color((0.9, 0.5, 0.3))
+            w.add_obj(A.Object(A.Sphere(c, 0.005), m))
+        w.add_light(A.SkyLight())
+        return w
+
+    # a low camera looking along the ground: most primary rays hit the ground hundreds of units out
+    cam = (A.Camera.new((-1.0, 0.0, 0.3), (0.5, 0.0, 0.2)).with_fov(60.0).with_aspect(2.0).with_sample_rate(4))
+    W, H, depth = 512, 256, 6   # enough rays per level for the level kernels (the tail kernel scans lists)
+    out = {}
+    try:
+        for mode in (0, 1):
+            dev.set_grid(mode)
+            out[mode] = make().render(cam, W, H, depth, seed=9, return_stats=True)
+    finally:
+        dev.set_grid(1)
+    assert np.array_equal(out[0][0], out[1][0])
+    assert list(out[0][1].rays_per_level[:depth]) == list(out[1][1].rays_per_level[:depth])
+    assert int(out[1][1].exact_rescan) > int(out[0][1].exact_rescan) + 1000   # the far bounce rays
