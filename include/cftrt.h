@@ -130,9 +130,9 @@ int cftrt_ctx_set_wave_cull(cftrt_ctx* ctx, int on);
  * triangles of a scene with >= 64 of them in a uniform grid; rays then test only the primitives of the cells they
  * cross and stop behind the nearest candidate.  The candidates go through the same exact f64 evaluation as those
  * of the list scan, so images are identical bit for bit with any mode.
- *   mode 0: lists only (the reference's linear scan);  1 (default): waves whose ray bundle is too wide for the
- *   wave-level cull walk the grid, and every wave does once the scene lists more than 4096 primitives;  2: every
- *   wave does.
+ *   mode 0: lists only (the reference's linear scan);  1 (default): the primary rays keep the lists with the
+ *   wave-level cull, every later trace level walks the grid - and the primary rays too once the scene lists more
+ *   than 4096 primitives;  2: every ray walks.
  *   cells_per_prim > 0 sets the grid resolution for scenes committed afterwards (default 1); <= 0 keeps it. */
 int cftrt_ctx_set_grid(cftrt_ctx* ctx, int mode, double cells_per_prim);
 /* Intersect-kernel variant: rays per lane of k_intersect / k_trace_level (1..4); 0 = the tuned default. */

@@ -358,9 +358,9 @@ class Device:
         self.check(self.lib.cftrt_ctx_set_wave_cull(self.h, int(bool(on))))
 
     def set_grid(self, mode, cells_per_prim=0.0):
-        """Uniform grid (an extension to the reference's linear scan): 0 lists only, 1 (default) waves the cone
-        cull does not serve, 2 every wave; cells_per_prim > 0 sizes the grid of scenes committed afterwards.
-        Images are identical with any mode."""
+        """Uniform grid (an extension to the reference's linear scan): 0 lists only, 1 (default) bounce rays walk it
+        (primary rays too in scenes of more than 4096 primitives), 2 every ray; cells_per_prim > 0 sizes the grid
+        of scenes committed afterwards.  Images are identical with any mode."""
         self.check(self.lib.cftrt_ctx_set_grid(self.h, int(mode), float(cells_per_prim)))
 
     def set_variant(self, v):
