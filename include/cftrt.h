@@ -12,8 +12,14 @@
  * panics on `unwrap`; SURVEY.md §8b "Errors").
  *
  * Ownership: the caller owns every host buffer; `cftrt_scene_set_*` copy; handles are freed only
- * by `*_destroy`.  Threading: a ctx is bound to one device and one stream and is NOT thread-safe;
+ * by `*_destroy`; destroy every scene BEFORE the ctx it was created on (a scene keeps a pointer to
+ * its ctx).  Threading: a ctx is bound to one device and one stream and is NOT thread-safe;
  * use one ctx (one host thread / one process) per GPU.  Scenes are immutable after commit.
+ * Device and stream: every call makes the ctx's device current for its own work and restores the
+ * caller's current device before it returns.  The work runs on the ctx's own non-blocking stream
+ * and the render calls return after that stream has drained; work the CALLER has queued on other
+ * streams for a buffer it passes in (e.g. clearing the accumulation image) must have completed
+ * before the call - the library does not wait on foreign streams.
  */
 #ifndef CFTRT_H
 #define CFTRT_H
@@ -88,6 +94,8 @@ typedef struct cftrt_camera {
 } cftrt_camera;
 
 #define CFTRT_MAX_LEVELS 256
+/* Size of the static device workspace of cftrt_render_device_static (bytes, per GPU the library runs on). */
+#define CFTRT_STATIC_SCRATCH_BYTES (256u << 20)
 
 /* Filled by the render calls.  "Rays" follow BASELINE.md §2: every trace() level with depth>0
  * plus one ray per (Phong hit, light). */
@@ -172,10 +180,28 @@ int cftrt_render(cftrt_scene* scene, const cftrt_camera* cam, uint32_t width, ui
                  uint32_t spp_begin, uint32_t spp_end, uint32_t max_depth, uint64_t seed,
                  float* accum_host, cftrt_stats* stats);
 /* Same, accumulating into a DEVICE buffer (W*H*3 floats on the ctx's device), e.g. a torch tensor
- * that is then reduced over ranks with RCCL.  The call returns after its stream has drained. */
+ * that is then reduced over ranks with RCCL.  The call returns after its stream has drained; pending
+ * work of the caller on that buffer must have finished before the call (see "Device and stream"). */
 int cftrt_render_device(cftrt_scene* scene, const cftrt_camera* cam, uint32_t width,
                         uint32_t height, uint32_t spp_begin, uint32_t spp_end, uint32_t max_depth,
                         uint64_t seed, void* accum_device, cftrt_stats* stats);
+
+/* The same render for callers that cannot allocate.  It has NO counterpart in the reference; it exists for hosts
+ * that must not call hipMalloc at this point: code under HIP graph capture, tight serving loops, harnesses that
+ * forbid allocation.  Same arguments and result as cftrt_render_device (for a sample range that cftrt_render_device
+ * renders in one pass the images are identical bit for bit; k_resolve adds samples one by one, so the cut into
+ * passes does not change the sum either), but the pass workspace (ray queues, radiance slots, level counters) is a
+ * file-scope device array of CFTRT_STATIC_SCRATCH_BYTES (256 MiB) that every GPU the library runs on holds until the
+ * process ends; the call makes no hipMalloc/hipFree and creates no event (cftrt_stats: ms_total only, the per-kernel
+ * times stay 0).  Limit: one sample of the image must fit - width*height*96 bytes (152 with PhongModel materials,
+ * +32/64 in the split pipeline) <= 256 MiB less 8 KiB, i.e. up to 2.79 M pixels (1920x1080 fits, 3840x2160 does
+ * not): CFTRT_ERR_LIMIT otherwise.  Larger sample counts run as several passes.  All calls on one GPU share that
+ * GPU's array (whatever the ctx): calls that overlap in time on one GPU race; the library clears the counters it
+ * needs at the start of every pass, nothing else must start at zero. */
+int cftrt_render_device_static(cftrt_scene* scene, const cftrt_camera* cam, uint32_t width,
+                               uint32_t height, uint32_t spp_begin, uint32_t spp_end,
+                               uint32_t max_depth, uint64_t seed, void* accum_device,
+                               cftrt_stats* stats);
 
 /* ---- parity hooks (one kernel each, host buffers) ------------------------------------------ */
 /* Camera::emit_rays for path ids [pid0, pid0+n): out_rays = n x 6 floats (pos, dir).

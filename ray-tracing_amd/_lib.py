@@ -7,6 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CFTRT_LIB") or os.path.join(_HERE, "csrc", "libcftrt.so")   # CFTRT_LIB: experiments only
 
 CFTRT_MAX_LEVELS = 256
+CFTRT_STATIC_SCRATCH_BYTES = 256 << 20
 
 
 class cftrt_material(C.Structure):
@@ -69,6 +70,8 @@ SYMBOLS = [
                                C.c_uint32, C.c_uint64, _F, C.POINTER(cftrt_stats)]),
     ("cftrt_render_device", C.c_int, [_P, C.POINTER(cftrt_camera), C.c_uint32, C.c_uint32, C.c_uint32,
                                       C.c_uint32, C.c_uint32, C.c_uint64, _P, C.POINTER(cftrt_stats)]),
+    ("cftrt_render_device_static", C.c_int, [_P, C.POINTER(cftrt_camera), C.c_uint32, C.c_uint32, C.c_uint32,
+                                             C.c_uint32, C.c_uint32, C.c_uint64, _P, C.POINTER(cftrt_stats)]),
     ("cftrt_generate", C.c_int, [_P, C.POINTER(cftrt_camera), C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64,
                                  C.c_uint64, C.c_int, _F]),
     ("cftrt_intersect", C.c_int, [_P, _F, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _I, _D, _F,

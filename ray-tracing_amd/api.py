@@ -547,16 +547,18 @@ class World:
         return (accum, st) if return_stats else accum
 
     def render_device(self, camera, width, height, depth, accum_ptr, seed=0x5EED0002, spp_begin=0, spp_end=None,
-                      device=None):
-        """Same, accumulating into a device buffer (e.g. torch tensor .data_ptr()) of W*H*3 float32."""
+                      device=None, static=False):
+        """Same, accumulating into a device buffer (e.g. torch tensor .data_ptr()) of W*H*3 float32.
+        static=True: cftrt_render_device_static, the entry point that allocates nothing (256 MiB static workspace;
+        one sample of the image must fit)."""
         h = self.commit(device)
         dev = self._dev
         if spp_end is None:
             spp_end = spp_begin + camera.sample_rate
         st = L.cftrt_stats()
         pod = camera._pod()
-        dev.check(dev.lib.cftrt_render_device(h, C.byref(pod), width, height, spp_begin, spp_end, depth, seed,
-                                              C.c_void_p(accum_ptr), C.byref(st)))
+        fn = dev.lib.cftrt_render_device_static if static else dev.lib.cftrt_render_device
+        dev.check(fn(h, C.byref(pod), width, height, spp_begin, spp_end, depth, seed, C.c_void_p(accum_ptr), C.byref(st)))
         return st
 
     # -- parity hooks

@@ -33,7 +33,28 @@ struct cftrt_ctx {
   uint32_t* host_counts = nullptr;   // pinned
   std::vector<hipEvent_t> events;
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+  unsigned char* static_scratch = nullptr;   // this device's copy of `scratch` (cftrt_render_device_static)
 };
+
+// Workspace of the entry point that allocates nothing (cftrt_render_device_static): ray queues, radiance and level
+// counters of a pass live in this file-scope array instead of hipMalloc'ed buffers.  Every GPU the library runs on
+// holds its own copy, at its own address, until the process ends.  In host code the NAME is only a stand-in for
+// the symbol: the device address comes from hipGetSymbolAddress (cftrt_ctx_create, with the ctx's device current)
+// and only that pointer is ever handed to kernels, memsets and copies.
+static __device__ __align__(256) unsigned char scratch[CFTRT_STATIC_SCRATCH_BYTES];
+
+// Entry points make the ctx's device current for their own calls and put the caller's device back on return.
+struct DeviceGuard {
+  int prev = -1;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device) err = hipSetDevice(device);
+    else prev = -1;
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define DEVICE_GUARD(ctx) DeviceGuard dev_guard_((ctx)->device); HIP_TRY(ctx, dev_guard_.err)
 
 struct cftrt_scene {
   cftrt_ctx* ctx = nullptr;
@@ -119,8 +140,16 @@ int cftrt_ctx_create(int device, cftrt_ctx** out) {
   }
   cftrt_ctx* ctx = new cftrt_ctx();
   ctx->device = device;
-  if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+  DeviceGuard guard(device);
+  if ((e = guard.err) != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
     g_create_error = std::string("ctx_create: ") + hipGetErrorString(e);
+    delete ctx;
+    return CFTRT_ERR_HIP;
+  }
+  // this device's address of the static workspace (each GPU has its own copy of the array); `device` is current here
+  if ((e = hipGetSymbolAddress((void**)&ctx->static_scratch, HIP_SYMBOL(scratch))) != hipSuccess || !ctx->static_scratch) {
+    g_create_error = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e);
+    hipStreamDestroy(ctx->stream);
     delete ctx;
     return CFTRT_ERR_HIP;
   }
@@ -140,7 +169,7 @@ int cftrt_ctx_create(int device, cftrt_ctx** out) {
 
 void cftrt_ctx_destroy(cftrt_ctx* ctx) {
   if (!ctx) return;
-  hipSetDevice(ctx->device);
+  DeviceGuard guard(ctx->device);
   hipStreamSynchronize(ctx->stream);
   DevBuf* bufs[] = {&ctx->qa[0], &ctx->qa[1], &ctx->qb[0], &ctx->qb[1], &ctx->qc[0], &ctx->qc[1], &ctx->h0[0],
                     &ctx->h0[1], &ctx->h1[0], &ctx->h1[1], &ctx->rad, &ctx->pqa, &ctx->pqb, &ctx->pqc,
@@ -204,7 +233,7 @@ int cftrt_scene_create(cftrt_ctx* ctx, cftrt_scene** out) {
 
 void cftrt_scene_destroy(cftrt_scene* s) {
   if (!s) return;
-  hipSetDevice(s->ctx->device);
+  DeviceGuard guard(s->ctx->device);
   hipStreamSynchronize(s->ctx->stream);
   for (void* p : s->dev_allocs) hipFree(p);
   delete s;
@@ -309,7 +338,7 @@ int cftrt_scene_commit(cftrt_scene* s) {
   if (!s) return CFTRT_ERR_INVALID;
   if (s->committed) return fail(s->ctx, CFTRT_ERR_STATE, "scene already committed");
   cftrt_ctx* ctx = s->ctx;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  DEVICE_GUARD(ctx);
   const int ns = (int)s->sph_r.size(), nt = (int)s->tri_obj.size();
   const int nm = (int)s->mats.size();
   for (int i = 0; i < ns; ++i)
@@ -802,12 +831,14 @@ enum { CLS_GEN = 0, CLS_ISECT, CLS_SHADE, CLS_SHADOW, CLS_RESOLVE, CLS_N };
 // one pair per launch.
 struct EvTimer {
   cftrt_ctx* ctx;
+  bool timing = true;                           // false: count launches only (no event is created or recorded)
   size_t used = 0;
   bool open = false;                            // the last span's end event has not been recorded yet
   std::vector<std::pair<size_t, int>> spans;    // (start event index, class)
   uint32_t launches[CLS_N] = {0};
   int begin(int cls) {
     launches[cls] += 1;
+    if (!timing) return 0;
     if (open && spans.back().second == cls) return 0;
     flush();
     if (used + 2 > ctx->events.size()) {
@@ -840,18 +871,25 @@ struct EvTimer {
   }
 };
 
-// Renders path ids [pid_base, pid_base + P) (P = npix * nsamples) into the radiance buffer and, when
-// accum_dev != null, resolves them into accum_dev.
-static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t P, uint32_t nsamples, uint32_t npix,
-                    uint32_t max_depth, uint64_t seed, int jitter, float* accum_dev, cftrt_stats* st, EvTimer& tm) {
-  cftrt_ctx* ctx = s->ctx;
-  SceneDev S = s->dev;
-  S.wave_cull = ctx->wave_cull;
-  S.grid_mode = S.gnx ? ctx->grid : 0;
-  if (S.grid_mode == 1 && S.n_sphF + S.n_msph + S.n_triF > 4096) S.grid_mode = 2;   // long lists: every wave walks
-  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+// Device buffers of one pass (P paths): the ray queues, the radiance slots, the Phong queue, the level counters.
+struct PassBufs {
+  QueueDev q[2];
+  HitDev hA, hB;
+  PhongQueueDev pq;
+  float4* rad;
+  uint32_t* counts;
+};
+static const size_t kCountWords = 2 * CFTRT_MAX_LEVELS + 8;   // [0..L] level counts, [L+1..2L] phong counts, then misc
+
+static uint64_t bytes_per_path(const cftrt_ctx* ctx, const SceneDev& S) {
+  const bool two_scans = S.any_motion && S.n_lights > 0;
+  return 80 + 16 + (ctx->split ? (two_scans ? 64 : 32) : 0) + (S.n_phong_mats ? 56 : 0);
+}
+
+// From the ctx's grow-only hipMalloc'ed workspace.
+static int bufs_from_ctx(cftrt_ctx* ctx, const SceneDev& S, uint32_t P, PassBufs* B) {
   const bool phong = S.n_phong_mats > 0;
-  const bool two_scans = S.any_motion && S.n_lights > 0;   // `looked` and trace each draw their own motion times
+  const bool two_scans = S.any_motion && S.n_lights > 0;
   int rc;
   for (int k = 0; k < 2; ++k) {
     if ((rc = ensure(ctx, ctx->qa[k], (size_t)P * 16))) return rc;
@@ -869,21 +907,80 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
     if ((rc = ensure(ctx, ctx->pqc, (size_t)P * 16))) return rc;
     if ((rc = ensure(ctx, ctx->pqd, (size_t)P * 8))) return rc;
   }
-  const size_t ncount = 2 * CFTRT_MAX_LEVELS + 8;   // [0..L] level counts, [L+1..2L] phong counts, then misc
-  if ((rc = ensure(ctx, ctx->counts, ncount * 4))) return rc;
-  uint32_t* counts = (uint32_t*)ctx->counts.p;
+  if ((rc = ensure(ctx, ctx->counts, kCountWords * 4))) return rc;
+  for (int k = 0; k < 2; ++k) B->q[k] = QueueDev{(float4*)ctx->qa[k].p, (float4*)ctx->qb[k].p, (float2*)ctx->qc[k].p};
+  B->hA = HitDev{(float4*)ctx->h0[0].p, (float4*)ctx->h1[0].p};
+  B->hB = two_scans ? HitDev{(float4*)ctx->h0[1].p, (float4*)ctx->h1[1].p} : B->hA;
+  B->pq = PhongQueueDev{(float4*)ctx->pqa.p, (float4*)ctx->pqb.p, (float4*)ctx->pqc.p, (uint2*)ctx->pqd.p};
+  B->rad = (float4*)ctx->rad.p;
+  B->counts = (uint32_t*)ctx->counts.p;
+  return CFTRT_OK;
+}
+
+// Carved out of the static array (`base` = its device address on the ctx's device, from hipGetSymbolAddress).
+// No allocation; fails if the pass does not fit.
+static const size_t kStaticHeader = 4096;   // the counters, and room for the 256-byte alignment of each carve
+static int bufs_from_static(cftrt_ctx* ctx, const SceneDev& S, uint32_t P, PassBufs* B) {
+  const bool phong = S.n_phong_mats > 0;
+  const bool two_scans = S.any_motion && S.n_lights > 0;
+  unsigned char* base = ctx->static_scratch;
+  size_t off = 0;
+  bool ok = true;
+  auto carve = [&](size_t bytes) -> void* {
+    off = (off + 255) & ~(size_t)255;
+    void* p = base + off;
+    off += bytes;
+    if (off > (size_t)CFTRT_STATIC_SCRATCH_BYTES) ok = false;
+    return p;
+  };
+  B->counts = (uint32_t*)carve(kCountWords * 4);
+  for (int k = 0; k < 2; ++k) {
+    B->q[k].a = (float4*)carve((size_t)P * 16);
+    B->q[k].b = (float4*)carve((size_t)P * 16);
+    B->q[k].c = (float2*)carve((size_t)P * 8);
+  }
+  B->rad = (float4*)carve((size_t)P * 16);
+  B->hA = B->hB = HitDev{nullptr, nullptr};
+  if (ctx->split) {
+    B->hA = HitDev{(float4*)carve((size_t)P * 16), (float4*)carve((size_t)P * 16)};
+    B->hB = two_scans ? HitDev{(float4*)carve((size_t)P * 16), (float4*)carve((size_t)P * 16)} : B->hA;
+  }
+  B->pq = PhongQueueDev{nullptr, nullptr, nullptr, nullptr};
+  if (phong)
+    B->pq = PhongQueueDev{(float4*)carve((size_t)P * 16), (float4*)carve((size_t)P * 16), (float4*)carve((size_t)P * 16),
+                          (uint2*)carve((size_t)P * 8)};
+  if (!ok) return fail(ctx, CFTRT_ERR_LIMIT, "pass beyond the static workspace (CFTRT_STATIC_SCRATCH_BYTES)");
+  return CFTRT_OK;
+}
+
+// Renders path ids [pid_base, pid_base + P) (P = npix * nsamples) into the radiance buffer and, when
+// accum_dev != null, resolves them into accum_dev.
+static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t P, uint32_t nsamples, uint32_t npix,
+                    uint32_t max_depth, uint64_t seed, int jitter, float* accum_dev, cftrt_stats* st, EvTimer& tm,
+                    bool use_static = false) {
+  cftrt_ctx* ctx = s->ctx;
+  SceneDev S = s->dev;
+  S.wave_cull = ctx->wave_cull;
+  S.grid_mode = S.gnx ? ctx->grid : 0;
+  if (S.grid_mode == 1 && S.n_sphF + S.n_msph + S.n_triF > 4096) S.grid_mode = 2;   // long lists: every wave walks
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  const bool phong = S.n_phong_mats > 0;
+  const bool two_scans = S.any_motion && S.n_lights > 0;   // `looked` and trace each draw their own motion times
+  int rc;
+  PassBufs B;
+  if ((rc = use_static ? bufs_from_static(ctx, S, P, &B) : bufs_from_ctx(ctx, S, P, &B))) return rc;
+  const size_t ncount = kCountWords;
+  uint32_t* counts = B.counts;
   uint32_t* phong_counts = counts + CFTRT_MAX_LEVELS + 1;
   uint32_t* xstats = counts + 2 * CFTRT_MAX_LEVELS + 2;   // [0] second exact evaluations, [1] f64 rescans
   hipStream_t st_ = ctx->stream;
   HIP_TRY(ctx, hipMemsetAsync(counts, 0, ncount * 4, st_));
-  HIP_TRY(ctx, hipMemcpyAsync(counts, &P, 4, hipMemcpyHostToDevice, st_));
+  HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)counts, (int)P, 1, st_));   // counts[0] = P (no host staging buffer)
 
-  QueueDev q[2];
-  for (int k = 0; k < 2; ++k) q[k] = QueueDev{(float4*)ctx->qa[k].p, (float4*)ctx->qb[k].p, (float2*)ctx->qc[k].p};
-  HitDev hA{(float4*)ctx->h0[0].p, (float4*)ctx->h1[0].p};
-  HitDev hB = two_scans ? HitDev{(float4*)ctx->h0[1].p, (float4*)ctx->h1[1].p} : hA;
-  PhongQueueDev pq{(float4*)ctx->pqa.p, (float4*)ctx->pqb.p, (float4*)ctx->pqc.p, (uint2*)ctx->pqd.p};
-  float4* rad = (float4*)ctx->rad.p;
+  QueueDev q[2] = {B.q[0], B.q[1]};
+  HitDev hA = B.hA, hB = B.hB;
+  PhongQueueDev pq = B.pq;
+  float4* rad = B.rad;
 
   if (tm.begin(CLS_GEN)) return fail(ctx, CFTRT_ERR_HIP, "hipEventCreate failed");
   const int tiled = (C.width % 32u == 0 && C.height % 8u == 0 && npix == C.width * C.height && P % npix == 0 && pid_base % npix == 0) ? 1 : 0;
@@ -956,31 +1053,36 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
 }
 
 static int render_impl(cftrt_scene* s, const cftrt_camera* cam, uint32_t width, uint32_t height, uint32_t spp_begin,
-                       uint32_t spp_end, uint32_t max_depth, uint64_t seed, float* accum_dev, cftrt_stats* stats) {
+                       uint32_t spp_end, uint32_t max_depth, uint64_t seed, float* accum_dev, cftrt_stats* stats,
+                       bool use_static = false) {
   cftrt_ctx* ctx = s->ctx;
   if (!s->committed) return fail(ctx, CFTRT_ERR_STATE, "scene not committed");
   if (spp_end < spp_begin) return fail(ctx, CFTRT_ERR_INVALID, "spp_end < spp_begin");
   if (max_depth > CFTRT_MAX_LEVELS) return fail(ctx, CFTRT_ERR_LIMIT, "max_depth beyond CFTRT_MAX_LEVELS (256)");
   CamDev C;
   if (int rc = make_cam(ctx, cam, width, height, &C)) return rc;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  DEVICE_GUARD(ctx);
   const uint64_t npix = (uint64_t)width * height;
   if (npix > (1ull << 31)) return fail(ctx, CFTRT_ERR_LIMIT, "image beyond 2^31 pixels");
-  const bool two_scans = s->dev.any_motion && s->dev.n_lights > 0;
-  const uint64_t bytes_per_path = 80 + 16 + (ctx->split ? (two_scans ? 64 : 32) : 0) + (s->dev.n_phong_mats ? 56 : 0);
-  uint64_t spp_pass = ctx->ws_limit / (bytes_per_path * npix);
+  // a pass renders whole samples of the image; the static workspace keeps 4 KiB + 256 B per buffer for its carving
+  const uint64_t limit = use_static ? (uint64_t)CFTRT_STATIC_SCRATCH_BYTES - kStaticHeader - 16 * 256 : ctx->ws_limit;
+  uint64_t spp_pass = limit / (bytes_per_path(ctx, s->dev) * npix);
   spp_pass = std::min<uint64_t>(spp_pass, 0xFFFFFF00ull / npix);
-  if (spp_pass == 0) return fail(ctx, CFTRT_ERR_LIMIT, "one sample per pixel does not fit the workspace limit");
+  if (spp_pass == 0)
+    return fail(ctx, CFTRT_ERR_LIMIT, use_static ? "one sample per pixel does not fit the static workspace (CFTRT_STATIC_SCRATCH_BYTES)"
+                                                 : "one sample per pixel does not fit the workspace limit");
   cftrt_stats st;
   memset(&st, 0, sizeof st);
   EvTimer tm{ctx};
+  tm.timing = !use_static;   // per-class kernel times need events created on demand: not in the call that allocates nothing
   double ms[CLS_N] = {0};
   uint32_t nl[CLS_N] = {0};
   HIP_TRY(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
   for (uint32_t sb = spp_begin; sb < spp_end;) {
     uint32_t ns = (uint32_t)std::min<uint64_t>(spp_pass, spp_end - sb);
     uint64_t pid_base = (uint64_t)sb * npix;
-    int rc = run_pass(s, C, pid_base, (uint32_t)(npix * ns), ns, (uint32_t)npix, max_depth, seed, 1, accum_dev, &st, tm);
+    int rc = run_pass(s, C, pid_base, (uint32_t)(npix * ns), ns, (uint32_t)npix, max_depth, seed, 1, accum_dev, &st, tm,
+                      use_static);
     if (rc) return rc;
     sb += ns;
     tm.collect(ms, nl);   // run_pass has synchronised: fold this pass's kernel spans
@@ -1010,13 +1112,21 @@ int cftrt_render_device(cftrt_scene* s, const cftrt_camera* cam, uint32_t width,
   return render_impl(s, cam, width, height, spp_begin, spp_end, max_depth, seed, (float*)accum_device, stats);
 }
 
+int cftrt_render_device_static(cftrt_scene* s, const cftrt_camera* cam, uint32_t width, uint32_t height,
+                               uint32_t spp_begin, uint32_t spp_end, uint32_t max_depth, uint64_t seed, void* accum_device,
+                               cftrt_stats* stats) {
+  if (!s) return CFTRT_ERR_INVALID;
+  if (!accum_device) return fail(s->ctx, CFTRT_ERR_INVALID, "null accumulation buffer");
+  return render_impl(s, cam, width, height, spp_begin, spp_end, max_depth, seed, (float*)accum_device, stats, true);
+}
+
 int cftrt_render(cftrt_scene* s, const cftrt_camera* cam, uint32_t width, uint32_t height, uint32_t spp_begin,
                  uint32_t spp_end, uint32_t max_depth, uint64_t seed, float* accum_host, cftrt_stats* stats) {
   if (!s) return CFTRT_ERR_INVALID;
   cftrt_ctx* ctx = s->ctx;
   if (!accum_host) return fail(ctx, CFTRT_ERR_INVALID, "null accumulation buffer");
   if (width == 0 || height == 0) return fail(ctx, CFTRT_ERR_INVALID, "zero image size");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  DEVICE_GUARD(ctx);
   size_t bytes = (size_t)width * height * 3 * sizeof(float);
   if (int rc = ensure(ctx, ctx->accum_tmp, bytes)) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->accum_tmp.p, accum_host, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -1036,7 +1146,7 @@ int cftrt_generate(cftrt_ctx* ctx, const cftrt_camera* cam, uint32_t width, uint
   CamDev C;
   if (int rc = make_cam(ctx, cam, width, height, &C)) return rc;
   if (n == 0) return CFTRT_OK;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  DEVICE_GUARD(ctx);
   int rc;
   if ((rc = ensure(ctx, ctx->qa[0], n * 16)) || (rc = ensure(ctx, ctx->qb[0], n * 16)) || (rc = ensure(ctx, ctx->qc[0], n * 8))) return rc;
   QueueDev q{(float4*)ctx->qa[0].p, (float4*)ctx->qb[0].p, (float2*)ctx->qc[0].p};
@@ -1062,7 +1172,7 @@ int cftrt_intersect(cftrt_scene* s, const float* rays, uint64_t n, uint64_t seed
   if (n && (!rays || !out_id)) return fail(ctx, CFTRT_ERR_INVALID, "null rays or out_id");
   if (n > (1ull << 28)) return fail(ctx, CFTRT_ERR_LIMIT, "intersect hook: more than 2^28 rays");
   if (n == 0) return CFTRT_OK;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  DEVICE_GUARD(ctx);
   // layout in misc: rays (24n) | id (4n) | t (8n) | n (12n) | p (12n) | counter
   size_t off_id = 24 * n, off_t = off_id + 4 * n;
   off_t = (off_t + 7) & ~(size_t)7;
@@ -1100,7 +1210,7 @@ int cftrt_trace_paths(cftrt_scene* s, const cftrt_camera* cam, uint32_t width, u
   cftrt_stats st;
   memset(&st, 0, sizeof st);
   if (n == 0) { if (stats) *stats = st; return CFTRT_OK; }
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  DEVICE_GUARD(ctx);
   EvTimer tm{ctx};
   if (max_depth == 0) {
     memset(out_rgb, 0, 12 * n);
@@ -1127,7 +1237,7 @@ int cftrt_resolve_rgb8(cftrt_ctx* ctx, const float* accum_host, uint64_t npix, d
   if (!(divisor > 0.0)) return fail(ctx, CFTRT_ERR_INVALID, "divisor must be positive");
   if (npix > (1ull << 31)) return fail(ctx, CFTRT_ERR_LIMIT, "image beyond 2^31 pixels");
   if (npix == 0) return CFTRT_OK;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  DEVICE_GUARD(ctx);
   size_t nf = 3 * npix;
   if (int rc = ensure(ctx, ctx->misc, nf * 4 + nf)) return rc;
   char* base = (char*)ctx->misc.p;

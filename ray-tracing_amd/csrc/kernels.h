@@ -1866,18 +1866,20 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_shadow(SceneDev S, PhongQueueDev 
 }
 
 // ------------------------------------------------------------------ resolve
-// one lane = one pixel: accum[pix] += sum over the pass's samples, in sample order (deterministic).
+// one lane = one pixel: the pass's samples are added to accum[pix] one by one, in sample order.  The running sum
+// starts from the value already there, so the result does not depend on how a call's sample range was cut into
+// passes (workspace limit, static workspace): one pass and many give the same bits.
 __global__ __launch_bounds__(CFT_BLOCK) void k_resolve(const float4* radiance, uint32_t npix, uint32_t nsamples,
                                                        float* accum) {
   for (uint32_t p = blockIdx.x * CFT_BLOCK + threadIdx.x; p < npix; p += gridDim.x * CFT_BLOCK) {
-    float r = 0.f, g = 0.f, b = 0.f;
+    float r = accum[3 * (size_t)p], g = accum[3 * (size_t)p + 1], b = accum[3 * (size_t)p + 2];
     for (uint32_t s = 0; s < nsamples; ++s) {
       float4 v = radiance[(size_t)s * npix + p];
       r += v.x; g += v.y; b += v.z;
     }
-    accum[3 * (size_t)p] += r;
-    accum[3 * (size_t)p + 1] += g;
-    accum[3 * (size_t)p + 2] += b;
+    accum[3 * (size_t)p] = r;
+    accum[3 * (size_t)p + 1] = g;
+    accum[3 * (size_t)p + 2] = b;
   }
 }
 
