@@ -208,13 +208,16 @@ int cftrt_render_device_static(cftrt_scene* scene, const cftrt_camera* cam, uint
  * jitter = 0 disables the pixel/lens draws (pixel centre, lens centre). */
 int cftrt_generate(cftrt_ctx* ctx, const cftrt_camera* cam, uint32_t width, uint32_t height,
                    uint64_t pid0, uint64_t n, uint64_t seed, int jitter, float* out_rays);
-/* Ray::hit for caller-supplied rays (n x 6 floats, dir used as given).  out_id = object index or
- * -1, out_t = distance (f64, the exact evaluation), out_normal = n x 3 shading normal after
- * HitInfo::new's flip, out_point = n x 3 hit point.  Motion times are keyed by
- * (seed, pid0+i, level, role) like the render path.  Any out_* except out_id may be NULL. */
+/* Ray::hit for caller-supplied rays (n x 6 floats).  The direction is used as given, like a
+ * struct-literal Ray (ray.rs:277-289): a direction that is not unit (| |d|^2 - 1 | > 1e-5) skips the
+ * f32 cull, which assumes unit directions, and is resolved by the exact f64 scan (slow: every
+ * primitive per ray).  out_id = object index or -1, out_t = distance (f64, the exact evaluation),
+ * out_normal = n x 3 shading normal after HitInfo::new's flip, out_point = n x 3 hit point,
+ * out_outward = HitInfo::outward (1 where the flip happened, ray.rs:237-241).  Motion times are keyed
+ * by (seed, pid0+i, level, role) like the render path.  Any out_* except out_id may be NULL. */
 int cftrt_intersect(cftrt_scene* scene, const float* rays, uint64_t n, uint64_t seed,
                     uint64_t pid0, uint32_t level, uint32_t role, int32_t* out_id, double* out_t,
-                    float* out_normal, float* out_point);
+                    float* out_normal, float* out_point, int32_t* out_outward);
 /* World::trace per path: out_rgb = n x 3 floats for path ids [pid0, pid0+n). */
 int cftrt_trace_paths(cftrt_scene* scene, const cftrt_camera* cam, uint32_t width, uint32_t height,
                       uint64_t pid0, uint64_t n, uint32_t max_depth, uint64_t seed, int jitter,

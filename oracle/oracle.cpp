@@ -155,7 +155,8 @@ static inline double hi_reflect_prob(const HitInfo& h, double ior) {  // ray.rs:
   double r0 = (1. - ior) / ((1. + ior) * (1. + ior));
   double cos = std::fabs(dot(h.dir_in, h.norm));
   double m = 1. - cos;
-  return r0 + (1. - r0) * (m * m * m * m * m);  // powi(5) by repeated multiplication
+  const double m2 = m * m;
+  return r0 + (1. - r0) * (m * (m2 * m2));  // powi(5): square-and-multiply, x * (x^2)^2 (what llvm.powi / __powidf2 computes)
 }
 
 // ---------------------------------------------------------------- Shapes (object.rs)
@@ -647,6 +648,14 @@ static inline Ray primary_ray(const Camera& cam, uint64_t width, uint64_t height
 
 // ================================================================= C API (ctypes)
 using namespace orc;
+template <typename F>
+static void parallel_ranges(uint64_t n, int nthreads, F&& f) {
+  if (nthreads <= 1 || n < 2) { f(0, n); return; }
+  std::vector<std::thread> th;
+  for (int i = 0; i < nthreads; ++i)
+    th.emplace_back([&, i]() { f(n * (uint64_t)i / (uint64_t)nthreads, n * (uint64_t)(i + 1) / (uint64_t)nthreads); });
+  for (auto& t : th) t.join();
+}
 extern "C" {
 
 struct orc_camera {  // mirrors the Camera builder (ray.rs:59-82,139)
@@ -779,6 +788,15 @@ void orc_hit(void* wp, const double* rays, uint64_t n, uint64_t seed, uint64_t p
   }
 }
 
+// Threaded forms for the large-scene tests: the same per-ray / per-path calls over disjoint index ranges.
+void orc_hit_mt(void* wp, const double* rays, uint64_t n, uint64_t seed, uint64_t pid0, uint32_t level, uint32_t role,
+                int32_t* out_id, double* out_t, double* out_n, double* out_p, int32_t* out_flags, int nthreads) {
+  parallel_ranges(n, nthreads, [&](uint64_t b, uint64_t e) {
+    orc_hit(wp, rays + 6 * b, e - b, seed, pid0 + b, level, role, out_id + b, out_t + b, out_n ? out_n + 3 * b : nullptr,
+            out_p ? out_p + 3 * b : nullptr, out_flags ? out_flags + b : nullptr);
+  });
+}
+
 // World::trace for path ids [pid0, pid0+n): out_rgb = n x 3 doubles.  Returns rays traced.
 uint64_t orc_trace_paths(void* wp, const orc_camera* c, uint64_t width, uint64_t height, uint64_t pid0,
                          uint64_t n, uint64_t depth, uint64_t seed, int jitter, double* out_rgb) {
@@ -794,6 +812,15 @@ uint64_t orc_trace_paths(void* wp, const orc_camera* c, uint64_t width, uint64_t
     rays += ctx.rays;
   }
   return rays;
+}
+
+uint64_t orc_trace_paths_mt(void* wp, const orc_camera* c, uint64_t width, uint64_t height, uint64_t pid0, uint64_t n,
+                            uint64_t depth, uint64_t seed, int jitter, double* out_rgb, int nthreads) {
+  std::atomic<uint64_t> total{0};
+  parallel_ranges(n, nthreads, [&](uint64_t b, uint64_t e) {
+    total += orc_trace_paths(wp, c, width, height, pid0 + b, e - b, depth, seed, jitter, out_rgb + 3 * b);
+  });
+  return total.load();
 }
 
 // The render loop the examples hand-roll (scene.rs:82-102, cornell.rs:31-39): accum[h*W+w] += trace

@@ -75,7 +75,7 @@ SYMBOLS = [
     ("cftrt_generate", C.c_int, [_P, C.POINTER(cftrt_camera), C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64,
                                  C.c_uint64, C.c_int, _F]),
     ("cftrt_intersect", C.c_int, [_P, _F, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _I, _D, _F,
-                                  _F]),
+                                  _F, _I]),
     ("cftrt_trace_paths", C.c_int, [_P, C.POINTER(cftrt_camera), C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64,
                                     C.c_uint32, C.c_uint64, C.c_int, _F, C.POINTER(cftrt_stats)]),
     ("cftrt_resolve_rgb8", C.c_int, [_P, _F, C.c_uint64, C.c_double, C.POINTER(C.c_uint8)]),

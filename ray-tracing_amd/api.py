@@ -80,11 +80,13 @@ class Square:
 
     @classmethod
     def from_points(cls, p0, p1, p2, p3):  # object.rs:169-174
-        s = cls.__new__(cls)
-        s._ctor = None
-        s.tri0 = Triangle(p0, p1, p2)
-        s.tri1 = Triangle(p1, p2, p3)
-        return s
+        """Not flattened to the device.  The reference's Square::hit_info is `tri0.or(tri1)` (object.rs:192): tri0 wins
+        whenever it is hit, even where tri1 is nearer.  For Square::new that never differs from the closest of the two
+        (coplanar triangles that share only the diagonal); for from_points, whose triangles (p0,p1,p2) and (p1,p2,p3)
+        overlap or leave the plane, it does, and the device's closest-hit rule over triangles would give other
+        results.  Build the two triangles as separate objects, or use Square.new."""
+        raise NotImplementedError("Square.from_points has no device counterpart (tri0-first rule, object.rs:192); "
+                                  "use Square(center, x, y, len) or two Triangle objects")
 
     def _flatten(self):
         return [], [(self.tri0.p0, self.tri0.p1, self.tri0.p2), (self.tri1.p0, self.tri1.p1, self.tri1.p2)]
@@ -562,8 +564,8 @@ class World:
         return st
 
     # -- parity hooks
-    def intersect(self, rays, seed=0, pid0=0, level=0, role=0, device=None):
-        """Ray::hit for n x 6 float32 rays -> (object id, t f64, shading normal, hit point)."""
+    def intersect(self, rays, seed=0, pid0=0, level=0, role=0, device=None, with_outward=False):
+        """Ray::hit for n x 6 float32 rays -> (object id, t f64, shading normal, hit point[, outward flag])."""
         h = self.commit(device)
         dev = self._dev
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
@@ -572,9 +574,10 @@ class World:
         t = np.empty(n, np.float64)
         nrm = np.empty((n, 3), np.float32)
         pt = np.empty((n, 3), np.float32)
+        outward = np.zeros(n, np.int32)
         dev.check(dev.lib.cftrt_intersect(h, _fptr(rays), n, seed, pid0, level, role, _iptr(ids), _dptr(t),
-                                          _fptr(nrm), _fptr(pt)))
-        return ids, t, nrm, pt
+                                          _fptr(nrm), _fptr(pt), _iptr(outward)))
+        return (ids, t, nrm, pt, outward) if with_outward else (ids, t, nrm, pt)
 
     def trace_paths(self, camera, width, height, pid0, n, depth, seed=0x5EED0002, jitter=True, device=None):
         h = self.commit(device)

@@ -29,7 +29,7 @@ struct cftrt_ctx {
   int split = 0;          // 0: fused k_trace_level per level (default); 1: k_intersect -> hit records -> k_shade
   int n_cu = 256;
   // grow-only workspace
-  DevBuf qa[2], qb[2], qc[2], h0[2], h1[2], rad, pqa, pqb, pqc, pqd, counts, accum_tmp, misc;
+  DevBuf qa[2], qb[2], qc[2], h0[2], h1[2], ht[2], rad, pqa, pqb, pqc, pqd, counts, accum_tmp, misc;
   uint32_t* host_counts = nullptr;   // pinned
   std::vector<hipEvent_t> events;
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
@@ -172,7 +172,7 @@ void cftrt_ctx_destroy(cftrt_ctx* ctx) {
   DeviceGuard guard(ctx->device);
   hipStreamSynchronize(ctx->stream);
   DevBuf* bufs[] = {&ctx->qa[0], &ctx->qa[1], &ctx->qb[0], &ctx->qb[1], &ctx->qc[0], &ctx->qc[1], &ctx->h0[0],
-                    &ctx->h0[1], &ctx->h1[0], &ctx->h1[1], &ctx->rad, &ctx->pqa, &ctx->pqb, &ctx->pqc,
+                    &ctx->h0[1], &ctx->h1[0], &ctx->h1[1], &ctx->ht[0], &ctx->ht[1], &ctx->rad, &ctx->pqa, &ctx->pqb, &ctx->pqc,
                     &ctx->pqd, &ctx->counts, &ctx->accum_tmp, &ctx->misc};
   for (DevBuf* b : bufs)
     if (b->p) hipFree(b->p);
@@ -883,7 +883,7 @@ static const size_t kCountWords = 2 * CFTRT_MAX_LEVELS + 8;   // [0..L] level co
 
 static uint64_t bytes_per_path(const cftrt_ctx* ctx, const SceneDev& S) {
   const bool two_scans = S.any_motion && S.n_lights > 0;
-  return 80 + 16 + (ctx->split ? (two_scans ? 64 : 32) : 0) + (S.n_phong_mats ? 56 : 0);
+  return 80 + 16 + (ctx->split ? (two_scans ? 80 : 40) : 0) + (S.n_phong_mats ? 56 : 0);
 }
 
 // From the ctx's grow-only hipMalloc'ed workspace.
@@ -899,6 +899,7 @@ static int bufs_from_ctx(cftrt_ctx* ctx, const SceneDev& S, uint32_t P, PassBufs
   for (int k = 0; ctx->split && k < (two_scans ? 2 : 1); ++k) {   // hit records: split pipeline only
     if ((rc = ensure(ctx, ctx->h0[k], (size_t)P * 16))) return rc;
     if ((rc = ensure(ctx, ctx->h1[k], (size_t)P * 16))) return rc;
+    if ((rc = ensure(ctx, ctx->ht[k], (size_t)P * 8))) return rc;
   }
   if ((rc = ensure(ctx, ctx->rad, (size_t)P * 16))) return rc;
   if (phong) {
@@ -909,8 +910,8 @@ static int bufs_from_ctx(cftrt_ctx* ctx, const SceneDev& S, uint32_t P, PassBufs
   }
   if ((rc = ensure(ctx, ctx->counts, kCountWords * 4))) return rc;
   for (int k = 0; k < 2; ++k) B->q[k] = QueueDev{(float4*)ctx->qa[k].p, (float4*)ctx->qb[k].p, (float2*)ctx->qc[k].p};
-  B->hA = HitDev{(float4*)ctx->h0[0].p, (float4*)ctx->h1[0].p};
-  B->hB = two_scans ? HitDev{(float4*)ctx->h0[1].p, (float4*)ctx->h1[1].p} : B->hA;
+  B->hA = HitDev{(float4*)ctx->h0[0].p, (float4*)ctx->h1[0].p, (double*)ctx->ht[0].p};
+  B->hB = two_scans ? HitDev{(float4*)ctx->h0[1].p, (float4*)ctx->h1[1].p, (double*)ctx->ht[1].p} : B->hA;
   B->pq = PhongQueueDev{(float4*)ctx->pqa.p, (float4*)ctx->pqb.p, (float4*)ctx->pqc.p, (uint2*)ctx->pqd.p};
   B->rad = (float4*)ctx->rad.p;
   B->counts = (uint32_t*)ctx->counts.p;
@@ -940,10 +941,10 @@ static int bufs_from_static(cftrt_ctx* ctx, const SceneDev& S, uint32_t P, PassB
     B->q[k].c = (float2*)carve((size_t)P * 8);
   }
   B->rad = (float4*)carve((size_t)P * 16);
-  B->hA = B->hB = HitDev{nullptr, nullptr};
+  B->hA = B->hB = HitDev{nullptr, nullptr, nullptr};
   if (ctx->split) {
-    B->hA = HitDev{(float4*)carve((size_t)P * 16), (float4*)carve((size_t)P * 16)};
-    B->hB = two_scans ? HitDev{(float4*)carve((size_t)P * 16), (float4*)carve((size_t)P * 16)} : B->hA;
+    B->hA = HitDev{(float4*)carve((size_t)P * 16), (float4*)carve((size_t)P * 16), (double*)carve((size_t)P * 8)};
+    B->hB = two_scans ? HitDev{(float4*)carve((size_t)P * 16), (float4*)carve((size_t)P * 16), (double*)carve((size_t)P * 8)} : B->hA;
   }
   B->pq = PhongQueueDev{nullptr, nullptr, nullptr, nullptr};
   if (phong)
@@ -989,18 +990,24 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
 
   uint32_t ub = P;   // upper bound on the live rays of the current level (a ray spawns at most one ray)
   uint32_t levels_run = 0;
+  // Motion key of the lights' `looked` scan: the reference scans once per light that looks (SkyLight, LightShape),
+  // keyed here by that light's index in world.lights (Point/Parallel lights never scan, light.rs:17-19).  With
+  // several such lights the scans share the first one's key (known deviations).
+  uint32_t looked_role = 0;
+  for (size_t i = 0; i < s->lights.size(); ++i)
+    if (s->lights[i].kind == CFTRT_LIGHT_SKY || s->lights[i].kind == CFTRT_LIGHT_SHAPE) { looked_role = (uint32_t)i; break; }
   for (uint32_t level = 0; level < max_depth; ++level) {
     const uint32_t grid = grid_for(ctx, ub, 8);
     int in = level & 1, outq = in ^ 1;
     const uint32_t nl = (uint32_t)S.n_lights;
     if (!ctx->split) {
       tm.begin(CLS_ISECT);   // the fused kernel is booked as the intersect class (ms_shade stays 0)
-      launch_trace_level(ctx, S, q[in], counts, level, max_depth, pid_base, k0, k1, two_scans, two_scans ? 0u : nl, nl,
+      launch_trace_level(ctx, S, q[in], counts, level, max_depth, pid_base, k0, k1, two_scans, two_scans ? looked_role : nl, nl,
                          q[outq], rad, pq, phong_counts, xstats, ub);
       tm.end();
     } else {
       tm.begin(CLS_ISECT);
-      launch_intersect(ctx, S, q[in], counts, level, pid_base, k0, k1, two_scans, two_scans ? 0u : nl, nl, hA, hB, xstats, ub);
+      launch_intersect(ctx, S, q[in], counts, level, pid_base, k0, k1, two_scans, two_scans ? looked_role : nl, nl, hA, hB, xstats, ub);
       tm.end();
       tm.begin(CLS_SHADE);
       hipLaunchKernelGGL(k_shade, dim3(grid), dim3(CFT_BLOCK), 0, st_, S, q[in], hA, hB, counts, level, max_depth,
@@ -1165,7 +1172,8 @@ int cftrt_generate(cftrt_ctx* ctx, const cftrt_camera* cam, uint32_t width, uint
 }
 
 int cftrt_intersect(cftrt_scene* s, const float* rays, uint64_t n, uint64_t seed, uint64_t pid0, uint32_t level,
-                    uint32_t role, int32_t* out_id, double* out_t, float* out_normal, float* out_point) {
+                    uint32_t role, int32_t* out_id, double* out_t, float* out_normal, float* out_point,
+                    int32_t* out_outward) {
   if (!s) return CFTRT_ERR_INVALID;
   cftrt_ctx* ctx = s->ctx;
   if (!s->committed) return fail(ctx, CFTRT_ERR_STATE, "scene not committed");
@@ -1173,10 +1181,10 @@ int cftrt_intersect(cftrt_scene* s, const float* rays, uint64_t n, uint64_t seed
   if (n > (1ull << 28)) return fail(ctx, CFTRT_ERR_LIMIT, "intersect hook: more than 2^28 rays");
   if (n == 0) return CFTRT_OK;
   DEVICE_GUARD(ctx);
-  // layout in misc: rays (24n) | id (4n) | t (8n) | n (12n) | p (12n) | counter
+  // layout in misc: rays (24n) | id (4n) | t (8n) | n (12n) | p (12n) | outward (4n) | counter
   size_t off_id = 24 * n, off_t = off_id + 4 * n;
   off_t = (off_t + 7) & ~(size_t)7;
-  size_t off_n = off_t + 8 * n, off_p = off_n + 12 * n, off_c = off_p + 12 * n, total = off_c + 16;
+  size_t off_n = off_t + 8 * n, off_p = off_n + 12 * n, off_o = off_p + 12 * n, off_c = off_o + 4 * n, total = off_c + 16;
   if (int rc = ensure(ctx, ctx->misc, total)) return rc;
   char* base = (char*)ctx->misc.p;
   HIP_TRY(ctx, hipMemcpyAsync(base, rays, 24 * n, hipMemcpyHostToDevice, ctx->stream));
@@ -1184,14 +1192,16 @@ int cftrt_intersect(cftrt_scene* s, const float* rays, uint64_t n, uint64_t seed
   SceneDev S = s->dev;
   S.wave_cull = ctx->wave_cull;
   S.grid_mode = S.gnx ? ctx->grid : 0;
+  if (S.grid_mode == 1 && S.n_sphF + S.n_msph + S.n_triF > 4096) S.grid_mode = 2;   // as the render path does
   hipLaunchKernelGGL(k_intersect_hook, dim3(grid_for(ctx, n, 8)), dim3(CFT_BLOCK), 0, ctx->stream, S,
                      (const float*)base, (uint32_t)n, pid0, level, role, (uint32_t)seed, (uint32_t)(seed >> 32),
                      (int32_t*)(base + off_id), (double*)(base + off_t), (float*)(base + off_n), (float*)(base + off_p),
-                     (uint32_t*)(base + off_c));
+                     (int32_t*)(base + off_o), (uint32_t*)(base + off_c));
   HIP_TRY(ctx, hipMemcpyAsync(out_id, base + off_id, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
   if (out_t) HIP_TRY(ctx, hipMemcpyAsync(out_t, base + off_t, 8 * n, hipMemcpyDeviceToHost, ctx->stream));
   if (out_normal) HIP_TRY(ctx, hipMemcpyAsync(out_normal, base + off_n, 12 * n, hipMemcpyDeviceToHost, ctx->stream));
   if (out_point) HIP_TRY(ctx, hipMemcpyAsync(out_point, base + off_p, 12 * n, hipMemcpyDeviceToHost, ctx->stream));
+  if (out_outward) HIP_TRY(ctx, hipMemcpyAsync(out_outward, base + off_o, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipGetLastError());
   return CFTRT_OK;

@@ -1170,9 +1170,10 @@ __device__ __forceinline__ void isect_park(const RayPack<R, NS>& P, float (*park
 template <int NS>
 __device__ __forceinline__ void isect_hit(const SceneDev& S, bool live, int r, int k, float ox, float oy, float oz,
                                           float dx, float dy, float dz, float (*park)[CFT_BLOCK], uint32_t* stats,
-                                          float4* h0, float4* h1) {
+                                          float4* h0, float4* h1, double* t64) {
   *h0 = make_float4(__builtin_inff(), __int_as_float(-1), 0.f, 0.f);
   *h1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  *t64 = __builtin_inf();
   uint32_t word = 0;
   Closest c;
   c.t = __builtin_inf();
@@ -1203,6 +1204,7 @@ __device__ __forceinline__ void isect_hit(const SceneDev& S, bool live, int r, i
     f3 nn = hit_normal(S, c.g, p, word);
     *h0 = make_float4((float)c.t, __int_as_float(c.g), (float)p.x, (float)p.y);
     *h1 = make_float4((float)p.z, nn.x, nn.y, nn.z);
+    *t64 = c.t;
   }
 }
 
@@ -1240,10 +1242,11 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_intersect(SceneDev S, QueueDev q,
 #pragma unroll
       for (int k = 0; k < NS; ++k) {
         float4 h0, h1;
-        isect_hit<NS>(S, live, r, k, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &h0, &h1);
+        double t64;
+        isect_hit<NS>(S, live, r, k, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &h0, &h1, &t64);
         if (live) {
-          if (k == 0) { out0.h0[i] = h0; out0.h1[i] = h1; }
-          else        { out1.h0[i] = h0; out1.h1[i] = h1; }
+          if (k == 0) { out0.h0[i] = h0; out0.h1[i] = h1; out0.t[i] = t64; }
+          else        { out1.h0[i] = h0; out1.h1[i] = h1; out1.t[i] = t64; }
         }
       }
     }
@@ -1256,23 +1259,38 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_intersect_hook(SceneDev S, const 
                                                               uint64_t pid0, uint32_t level, uint32_t role,
                                                               uint32_t k0, uint32_t k1, int32_t* out_id,
                                                               double* out_t, float* out_n, float* out_p,
-                                                              uint32_t* stats) {
-  for (uint32_t i = blockIdx.x * CFT_BLOCK + threadIdx.x; i < n; i += gridDim.x * CFT_BLOCK) {
-    const float* r = rays + 6 * (size_t)i;
+                                                              int32_t* out_outward, uint32_t* stats) {
+  // (whole waves run the loop together: the f64 scan below is done by the wave)
+  for (uint32_t i0 = blockIdx.x * CFT_BLOCK + (threadIdx.x & ~63u); i0 < n; i0 += gridDim.x * CFT_BLOCK) {
+    const uint32_t i = i0 + (threadIdx.x & 63u);
+    const bool live = i < n;
+    const float* r = rays + 6 * (size_t)(live ? i : i0);
     float ox = r[0], oy = r[1], oz = r[2], dx = r[3], dy = r[4], dz = r[5];
     uint64_t pid = pid0 + i;
     uint32_t scan_word =
         philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), level, CFT_PURPOSE_SCAN0 + role, k0, k1).x;
-    Closest c = closest_hit(S, ox, oy, oz, dx, dy, dz, scan_word, stats);
+    // The f32 cull and the grid walk assume |d| = 1 (the render path's rays are unit to ~1e-7: Ray::new normalises,
+    // reflect / refract keep the length).  The hook takes the direction as given, like a struct-literal Ray
+    // (ray.rs:277-289): a ray whose direction is not unit goes straight to the exact f64 scan, whose sphere formula
+    // carries a = |d|^2 as the reference's does (object.rs:273-286).
+    const float l2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    const bool unit_dir = fabsf(l2 - 1.0f) <= 1e-5f;
+    Closest c;
+    c.t = __builtin_inf(); c.g = -1;
+    if (live && unit_dir) c = closest_hit(S, ox, oy, oz, dx, dy, dz, scan_word, stats);
+    const d3 o = d3{(double)ox, (double)oy, (double)oz};
+    const d3 d = d3{(double)dx, (double)dy, (double)dz};
+    exact_scan_all_wave(S, live && !unit_dir, o, d, scan_word, &c.t, &c.g);
+    if (!live) continue;
     d3 nn = d3{0., 0., 0.}, p = d3{0., 0., 0.};
+    int outward = 0;
     if (c.g >= 0) {
-      d3 o = d3{(double)ox, (double)oy, (double)oz};
-      d3 d = d3{(double)dx, (double)dy, (double)dz};
       p = o + d * c.t;
       nn = dunit(exact_normal(S, c.g, p, scan_word));
       d3 din = dunit(d);
-      if (ddot(nn, din) > -1e-3) nn = d3{-nn.x, -nn.y, -nn.z};
+      if (ddot(nn, din) > -1e-3) { nn = d3{-nn.x, -nn.y, -nn.z}; outward = 1; }   // ray.rs:237-241
     }
+    if (out_outward) out_outward[i] = outward;
     out_id[i] = c.g >= 0 ? S.prim_obj[c.g] : -1;
     out_t[i] = c.t;
     out_n[3 * (size_t)i] = (float)nn.x; out_n[3 * (size_t)i + 1] = (float)nn.y; out_n[3 * (size_t)i + 2] = (float)nn.z;
@@ -1312,7 +1330,8 @@ __device__ __forceinline__ bool hi_refract(const HitInfoF& h, float ratio, f3* p
 __device__ __forceinline__ float hi_reflect_prob(const HitInfoF& h, float ior) {  // ray.rs:312-316
   float r0 = (1.0f - ior) / ((1.0f + ior) * (1.0f + ior));   // NOT squared, as in the reference
   float m = 1.0f - fabsf(dot3(h.din, h.n));
-  return r0 + (1.0f - r0) * (m * m * m * m * m);
+  const float m2 = m * m;
+  return r0 + (1.0f - r0) * (m * (m2 * m2));   // powi(5) = x * (x^2)^2
 }
 
 // Static hit of a LightShape's own shape (Shape::hit_info, no motion), f64: light shapes are few.
@@ -1379,7 +1398,7 @@ __device__ __forceinline__ bool shade_one(const SceneDev& S, const H& hit, f3 po
     } else if (L.kind == 1) {                // LightShape::looked, light.rs:233-242
       double tl;
       if (light_shape_hit(S, L, pos, dir, &tl)) {
-        if (primA < 0 || tl < (double)A0.x) { see = true; col = col + mk3(L.r, L.g, L.b); }
+        if (primA < 0 || tl < hit.tA()) { see = true; col = col + mk3(L.r, L.g, L.b); }   // f64 against f64 (light.rs:236)
       }
     }
   }
@@ -1447,12 +1466,15 @@ __device__ __forceinline__ bool shade_one(const SceneDev& S, const H& hit, f3 po
 struct HitFromRecords {   // the split pipeline: hit records written by k_intersect, loaded on demand
   HitDev A, B;
   uint32_t i;
+  __device__ __forceinline__ double tA() const { return A.t[i]; }
   __device__ __forceinline__ float4 A0() const { return A.h0[i]; }
   __device__ __forceinline__ float4 B0() const { return B.h0[i]; }
   __device__ __forceinline__ float4 B1() const { return B.h1[i]; }
 };
 struct HitInRegisters {   // the fused pipeline
   float4 a0, b0, b1;
+  double ta;   // exact distance of the lights' `looked` scan
+  __device__ __forceinline__ double tA() const { return ta; }
   __device__ __forceinline__ float4 A0() const { return a0; }
   __device__ __forceinline__ float4 B0() const { return b0; }
   __device__ __forceinline__ float4 B1() const { return b1; }
@@ -1657,9 +1679,12 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(SceneDev S, QueueD
         an = q.a[j]; bn = q.b[j]; cn = q.c[j];
       }
       HitInRegisters hit;
-      isect_hit<NS>(S, live, r, 0, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.a0, &hit.b1);
+      isect_hit<NS>(S, live, r, 0, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.a0, &hit.b1, &hit.ta);
       hit.b0 = hit.a0;
-      if (NS == 2) isect_hit<NS>(S, live, r, 1, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.b0, &hit.b1);
+      if (NS == 2) {
+        double tb;
+        isect_hit<NS>(S, live, r, 1, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.b0, &hit.b1, &tb);
+      }
       f3 thr = mk3(b.z, b.w, c.x), npos, ndir;
       const bool alive = live && shade_one(S, hit, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), &thr, __float_as_uint(c.y), level,
                                            max_depth, pid_base, k0, k1, radiance, pq, phong_counts, &npos, &ndir);
@@ -1761,9 +1786,12 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_tail(SceneDev S, QueueDe
       const float4 b = q.b[live ? i : wb];
       const float2 c = q.c[live ? i : wb];
       HitInRegisters hit;
-      isect_hit<NS>(S, live, r, 0, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.a0, &hit.b1);
+      isect_hit<NS>(S, live, r, 0, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.a0, &hit.b1, &hit.ta);
       hit.b0 = hit.a0;
-      if (NS == 2) isect_hit<NS>(S, live, r, 1, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.b0, &hit.b1);
+      if (NS == 2) {
+        double tb;
+        isect_hit<NS>(S, live, r, 1, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.b0, &hit.b1, &tb);
+      }
       f3 thr = mk3(b.z, b.w, c.x), npos, ndir;
       const bool alive = live && shade_one(S, hit, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), &thr, __float_as_uint(c.y), level,
                                            max_depth, pid_base, k0, k1, radiance, pq, phong_counts, &npos, &ndir);

@@ -89,8 +89,9 @@ struct QueueDev {
   float4* b;   // dy, dz, thr_r, thr_g
   float2* c;   // thr_b, path id (uint bits)
 };
-// Hit record: 32 B in two streams.
+// Hit record: 40 B in three streams.
 struct HitDev {
-  float4* h0;  // t, prim (int bits; -1 = miss), px, py
+  float4* h0;  // t (f32-rounded), prim (int bits; -1 = miss), px, py
   float4* h1;  // pz, nx, ny, nz   (geometric unit normal before HitInfo::new's flip)
+  double* t;   // the exact f64 distance (+inf on a miss): LightShape::looked compares distances in f64 (light.rs:236)
 };

@@ -43,9 +43,12 @@ def lib():
                                     C.c_uint64, C.c_int, _D]
         L.orc_hit.argtypes = [C.c_void_p, _D, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                               C.POINTER(C.c_int32), _D, _D, _D, C.POINTER(C.c_int32)]
+        L.orc_hit_mt.argtypes = L.orc_hit.argtypes + [C.c_int]
         L.orc_trace_paths.restype = C.c_uint64
         L.orc_trace_paths.argtypes = [C.c_void_p, C.POINTER(orc_camera), C.c_uint64, C.c_uint64, C.c_uint64,
                                       C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, _D]
+        L.orc_trace_paths_mt.restype = C.c_uint64
+        L.orc_trace_paths_mt.argtypes = L.orc_trace_paths.argtypes + [C.c_int]
         L.orc_render.restype = C.c_uint64
         L.orc_render.argtypes = [C.c_void_p, C.POINTER(orc_camera), C.c_uint64, C.c_uint64, C.c_uint64,
                                  C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, _D]
@@ -144,7 +147,7 @@ class OracleWorld:
         except Exception:
             pass
 
-    def hit(self, rays, seed=0, pid0=0, level=0, role=0):
+    def hit(self, rays, seed=0, pid0=0, level=0, role=0, nthreads=1):
         rays = np.ascontiguousarray(rays, np.float64).reshape(-1, 6)
         n = len(rays)
         ids = np.empty(n, np.int32)
@@ -152,16 +155,16 @@ class OracleWorld:
         nrm = np.empty((n, 3), np.float64)
         pt = np.empty((n, 3), np.float64)
         fl = np.empty(n, np.int32)
-        lib().orc_hit(self.h, rays.ctypes.data_as(_D), n, seed, pid0, level, role,
-                      ids.ctypes.data_as(C.POINTER(C.c_int32)), t.ctypes.data_as(_D), nrm.ctypes.data_as(_D),
-                      pt.ctypes.data_as(_D), fl.ctypes.data_as(C.POINTER(C.c_int32)))
+        lib().orc_hit_mt(self.h, rays.ctypes.data_as(_D), n, seed, pid0, level, role,
+                         ids.ctypes.data_as(C.POINTER(C.c_int32)), t.ctypes.data_as(_D), nrm.ctypes.data_as(_D),
+                         pt.ctypes.data_as(_D), fl.ctypes.data_as(C.POINTER(C.c_int32)), int(nthreads))
         return ids, t, nrm, pt, fl
 
-    def trace_paths(self, cam, width, height, pid0, n, depth, seed, jitter=True):
+    def trace_paths(self, cam, width, height, pid0, n, depth, seed, jitter=True, nthreads=1):
         out = np.empty((n, 3), np.float64)
         pod = camera_pod(cam)
-        rays = lib().orc_trace_paths(self.h, C.byref(pod), width, height, pid0, n, depth, seed, int(jitter),
-                                     out.ctypes.data_as(_D))
+        rays = lib().orc_trace_paths_mt(self.h, C.byref(pod), width, height, pid0, n, depth, seed, int(jitter),
+                                        out.ctypes.data_as(_D), int(nthreads))
         return out, rays
 
     def render(self, cam, width, height, depth, seed, spp_begin=0, spp_end=None, nthreads=8):

@@ -18,11 +18,13 @@ REL = 1e-5          # north_star tolerance for hit distance / normal
 SEED = 0x5EED0002
 
 
-def _check_hits(world, ow, rays, seed=SEED, pid0=0, level=0, role=0, expect_exact_t=True):
-    ids, t, nrm, pt = world.intersect(rays, seed=seed, pid0=pid0, level=level, role=role)
-    oid, ot, on, op, _ = ow.hit(rays.astype(np.float64), seed=seed, pid0=pid0, level=level, role=role)
+def _check_hits(world, ow, rays, seed=SEED, pid0=0, level=0, role=0, expect_exact_t=True, nthreads=16):
+    ids, t, nrm, pt, outw = world.intersect(rays, seed=seed, pid0=pid0, level=level, role=role, with_outward=True)
+    oid, ot, on, op, ofl = ow.hit(rays.astype(np.float64), seed=seed, pid0=pid0, level=level, role=role, nthreads=nthreads)
     assert np.array_equal(ids, oid), f"{(ids != oid).sum()} object ids differ"
     hit = oid >= 0
+    # HitInfo::outward (ray.rs:237-241), decided in f64 on both sides from the same ray and the same exact t
+    assert np.array_equal(outw[hit], ofl[hit] & 1), f"{(outw[hit] != (ofl[hit] & 1)).sum()} outward flags differ"
     assert np.all(np.isinf(t[~hit]))
     assert np.all(np.abs(t[hit] - ot[hit]) <= REL * np.abs(ot[hit]))
     assert np.abs(nrm[hit] - on[hit]).max(initial=0) <= REL
@@ -142,6 +144,127 @@ def test_hits_s20k(rt, orc):
     W, H = 240, 135
     rays = rt.default_device().generate(cam, W, H, 0, W * H, SEED, True)
     _check_hits(world, ow, rays)
+
+
+def test_hits_s20k_full_scene(rt, orc):
+    """BASELINE.json configs[4] as it is benchmarked: all 20 001 primitives (19 000 spheres, 1 000 triangles in 500
+    squares, the ground).  Above 4 096 listed primitives every ray walks the grid (mode 2), which the 4.2 k-primitive
+    subset above never reaches.  Jittered primaries and incoherent rays from inside the scene: ids, distances
+    (bit for bit) and outward flags against the oracle's linear scan."""
+    world, cam = rt.scenes.s20k()
+    assert len(world.objects) == 19501
+    ow = orc.OracleWorld(world)
+    W, H = 224, 126
+    rays = rt.default_device().generate(cam, W, H, 0, W * H, SEED, True)
+    assert _check_hits(world, ow, rays) > 0.5 * W * H
+    rng = np.random.default_rng(20)
+    n = 30000
+    pos = np.c_[rng.uniform(-11.5, 11.5, n), rng.uniform(-11.5, 11.5, n), rng.uniform(0.0005, 1.2, n)]
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    assert _check_hits(world, ow, np.c_[pos, d].astype(np.float32)) > 0.3 * n
+    # with the grid switched off the hook scans the lists: same answers (a fresh commit is not needed: per-call mode)
+    dev = rt.default_device()
+    dev.set_grid(0)
+    try:
+        _check_hits(world, ow, rays[:4096])
+    finally:
+        dev.set_grid(1)
+
+
+def test_per_path_radiance_s20k_full_scene(rt, orc):
+    """The whole loop on the full S20k scene, depth 50, same Philox keys as the oracle."""
+    world, cam = rt.scenes.s20k()
+    W, H, spp, depth = 96, 54, 2, 50
+    n = W * H * spp
+    g, st = world.trace_paths(cam, W, H, 0, n, depth, seed=11)
+    o, orays = orc.OracleWorld(world).trace_paths(cam, W, H, 0, n, depth, 11, nthreads=16)
+    differing = (np.abs(g - o).max(axis=1) > 1e-3).mean()
+    assert differing < 0.005, f"{differing:.4f} of the paths differ"
+    assert abs(int(st.rays) - orays) <= 0.002 * orays
+    assert np.abs(g.mean(0) - o.mean(0)).max() < 0.01 * o.mean()
+
+
+def test_hook_takes_non_unit_directions(rt, orc):
+    """cftrt_intersect uses the direction as given (a struct-literal Ray); the f32 cull assumes |d| = 1, so such rays
+    go to the exact f64 scan.  |d| = 0.5 and 3 against the oracle, which never normalises either (orc_hit)."""
+    world, cam = rt.scenes.s500()
+    ow = orc.OracleWorld(world)
+    rays = rt.default_device().generate(cam, 64, 36, 0, 64 * 36, SEED, True)
+    for scale in (0.5, 3.0, 1.0 + 3e-5):
+        r = rays.copy()
+        r[:, 3:] *= np.float32(scale)
+        _check_hits(world, ow, r)
+    wt = rt.World.empty()      # triangles and a moving sphere too
+    wt.add_obj(rt.Object(rt.Cube((0, 0, 0), (1, 0, 0), (0, 1, 0), 4.0), rt.LambertianModel(0.5)))
+    wt.add_obj(rt.Object(rt.Sphere((0.3, 0.2, -0.5), 0.7), rt.LambertianModel(0.5)).moved((0.0, 0.3, 0.1)))
+    rng = np.random.default_rng(8)
+    n = 5000
+    r = np.c_[rng.uniform(-1.5, 1.5, (n, 3)), rng.normal(size=(n, 3)) * rng.uniform(0.2, 4.0, (n, 1))].astype(np.float32)
+    assert _check_hits(wt, orc.OracleWorld(wt), r, seed=5, pid0=77, level=2, role=1) == n
+
+
+def test_outward_flag_in_the_grazing_band(rt, orc):
+    """HitInfo::new flips the normal when n.d > -EPS, so hits with n.d in (-EPS, 0] are flagged `outward` although
+    the ray comes from outside.  Rays that graze a unit sphere with impact parameter 1 - [0, 2e-6]
+    land inside that band; the flag must equal the oracle's on every one of them, and both values must occur."""
+    w = rt.World.empty()
+    w.add_obj(rt.Object(rt.Sphere((0, 0, 0), 1.0), rt.LambertianModel(0.5)))
+    w.add_obj(rt.Object(rt.Triangle((-3, -3, 2.0), (3, -3, 2.0), (0, 3, 2.0005)), rt.LambertianModel(0.5)))
+    ow = orc.OracleWorld(w)
+    rng = np.random.default_rng(3)
+    n = 20000
+    b = 1.0 - rng.uniform(0.0, 2e-6, n)
+    ang = rng.uniform(0, 2 * np.pi, n)
+    pos = np.c_[b * np.cos(ang), b * np.sin(ang), np.full(n, -5.0)]
+    d = np.tile([0.0, 0.0, 1.0], (n, 1))
+    # and rays that meet the triangle at a glancing angle from either side
+    m = 20000
+    p2 = np.c_[rng.uniform(-2.5, 2.5, m), np.full(m, -6.0), 2.0 + rng.uniform(-0.02, 0.02, m)]
+    tgt = np.c_[rng.uniform(-1, 1, m), rng.uniform(-1, 1, m), np.full(m, 2.0002)]
+    d2 = tgt - p2
+    d2 /= np.linalg.norm(d2, axis=1)[:, None]
+    rays = np.r_[np.c_[pos, d], np.c_[p2, d2]].astype(np.float32)
+    ids, t, nrm, pt, outw = w.intersect(rays, with_outward=True)
+    _check_hits(w, ow, rays)
+    sph = ids[:n] == 0
+    assert sph.sum() > 0.3 * n and 0 < outw[:n][sph].sum() < sph.sum()      # the band is populated on both sides
+    tri = ids[n:] == 1
+    assert tri.sum() > 0.3 * m and 0 < outw[n:][tri].sum() < tri.sum()
+
+
+def test_light_shape_almost_on_a_wall(rt, orc):
+    """LightShape::looked sees the light iff its shape is hit NEARER than the world (light.rs:233-242), f64 against
+    f64.  A light square 1e-7 above a wall: the two distances differ by less than an f32 ulp, so comparing against an
+    f32-rounded world distance would flip about half the rays.  Per path against the oracle."""
+    w = rt.World.empty()
+    w.add_obj(rt.Object(rt.Square((0.0, 0.0, 0.0), (1.0, 0.0, 0.0), (0.0, 1.0, 0.0), 6.0), rt.LambertianModel(0.8)))
+    w.add_obj(rt.Object(rt.Sphere((0.5, -0.3, 0.8), 0.4), rt.Metal(0.1, 0.9)))
+    w.add_light(rt.LightShape(rt.Square((0.0, 0.0, 1e-7), (1.0, 0.0, 0.0), (0.0, 1.0, 0.0), 2.0)))
+    cam = rt.Camera.new((2.5, -2.0, 3.0), (0.0, 0.0, 0.0)).with_fov(50.0).with_aspect(1.5)
+    W, H, spp = 120, 80, 2
+    n = W * H * spp
+    g, st = w.trace_paths(cam, W, H, 0, n, 6, seed=5)
+    o, orays = orc.OracleWorld(w).trace_paths(cam, W, H, 0, n, 6, 5)
+    lit = (o.max(axis=1) > 0).mean()
+    assert 0.05 < lit < 0.95
+    assert (np.abs(g - o).max(axis=1) > 1e-3).mean() < 0.005
+    assert abs(int(st.rays) - orays) <= 0.002 * orays
+
+
+def test_moving_scene_with_sky_as_second_light(rt, orc):
+    """The `looked` scan of a light draws its motion times under the light's own index (oracle.cpp World::trace ->
+    looked(.., role = i)).  scene.rs with motion blur and lights [PointLight, SkyLight]: the sky is light 1."""
+    world, cam = rt.scenes.scene_rs()
+    world.lights = [rt.PointLight((0.0, 0.0, 5.0)), rt.SkyLight()]
+    world._invalidate()
+    W, H, spp, depth = 80, 50, 4, 10
+    n = W * H * spp
+    g, st = world.trace_paths(cam, W, H, 0, n, depth, seed=11)
+    o, orays = orc.OracleWorld(world).trace_paths(cam, W, H, 0, n, depth, 11, nthreads=8)
+    differing = (np.abs(g - o).max(axis=1) > 1e-3).mean()
+    assert differing < 0.005, f"{differing:.4f} of the paths differ"
+    assert abs(int(st.rays) - orays) <= 0.002 * orays
 
 
 def test_known_answers(rt):
@@ -281,7 +404,7 @@ def _rmse(a, b):
 @pytest.mark.parametrize("name,W,H,spp,depth", [("scene_rs", 160, 100, 64, 10), ("cornell", 120, 90, 128, 10)])
 def test_converged_image_rmse(rt, orc, name, W, H, spp, depth):
     """RMSE(GPU, oracle) <= 1.5 x RMSE(oracle seed A, oracle seed B) on the linear image, and the mean image
-    brightness within 1 % (SURVEY §8c tolerance).  scene_rs runs with motion blur ON."""
+    brightness within 0.5 % (SURVEY §8c tolerance).  scene_rs runs with motion blur ON."""
     world, cam = {"scene_rs": rt.scenes.scene_rs, "cornell": rt.scenes.cornell_rs}[name]()
     cam = cam.with_sample_rate(spp)
     ow = orc.OracleWorld(world)
@@ -292,7 +415,7 @@ def test_converged_image_rmse(rt, orc, name, W, H, spp, depth):
     self_rmse = _rmse(a, b)
     assert _rmse(g, a) <= 1.5 * self_rmse and _rmse(g, b) <= 1.5 * self_rmse
     ref = 0.5 * (a.mean() + b.mean())
-    assert abs(g.mean() - ref) <= 0.01 * ref
+    assert abs(g.mean() - ref) <= 0.005 * ref                     # mean brightness within 0.5 %
     psnr = 10 * np.log10(1.0 / max(_rmse(g, 0.5 * (a + b)) ** 2, 1e-12))
     print(f"{name}: rmse_self {self_rmse:.4f} rmse_gpu {_rmse(g, a):.4f} psnr vs oracle mean {psnr:.1f} dB")
     # the 8-bit resolve (scene.rs:122-127) on the device agrees with the oracle's on the same accumulation
@@ -301,7 +424,9 @@ def test_converged_image_rmse(rt, orc, name, W, H, spp, depth):
 
 
 def test_golden_image_statistics(rt):
-    """GPU render against the committed oracle images (different Philox seed): mean within 2 %."""
+    """GPU render against the committed oracle images (different Philox seed): mean within 2 % - the fixtures are
+    small (48x27 and 40x30 pixels at 4-16 spp), so the seed-to-seed standard error of the mean alone is ~0.5 %; the
+    0.5 % bar of SURVEY 8c is applied where the sample count supports it (test_converged_image_rmse)."""
     for name, fn, W, H in [("cornell", rt.scenes.cornell_rs, 40, 30), ("s500", rt.scenes.s500, 48, 27)]:
         gold = np.load(os.path.join(GOLD, f"image_{name}.npz"))
         world, cam = fn()
@@ -518,6 +643,38 @@ def test_full_size_properties(rt, orc):
     lo = world.render(cam, W, H, 50, spp_begin=0, spp_end=32)
     hi = world.render(cam, W, H, 50, spp_begin=32, spp_end=64)
     assert np.allclose(lo + hi, acc, rtol=1e-5, atol=1e-4)
+
+
+def test_c4_full_size_multipass(rt, orc):
+    """BASELINE.json configs[3] at its size: 3840x2160, the last samples of the 1024 (path ids beyond 2^33), through
+    the multi-pass path (a 1 GiB workspace holds one sample of the 8.3 M pixels: 796 MB).  Size-independent
+    properties, linearity over the sample range, and the image box-filtered 40x against a low-resolution oracle
+    render of the same camera."""
+    world, cam = rt.scenes.s500(width=3840, height=2160)
+    W, H, b, e = 3840, 2160, 1020, 1024
+    dev = rt.default_device()
+    dev.set_workspace_limit(1 << 30)
+    try:
+        acc, st = world.render(cam, W, H, 50, spp_begin=b, spp_end=e, return_stats=True)
+        lo = world.render(cam, W, H, 50, spp_begin=b, spp_end=b + 2)
+        hi = world.render(cam, W, H, 50, spp_begin=b + 2, spp_end=e)
+    finally:
+        dev.set_workspace_limit(40 << 30)
+    spp = e - b
+    assert int(st.passes) == spp
+    lv = list(st.rays_per_level[: int(st.levels)])
+    assert lv[0] == W * H * spp == int(st.paths)
+    assert all(lv[i] >= lv[i + 1] for i in range(len(lv) - 1))
+    assert sum(lv) == int(st.rays)
+    assert np.isfinite(acc).all() and acc.min() >= 0.0 and acc.max() <= spp * 1.0 + 1e-3
+    assert np.allclose(lo + hi, acc, rtol=1e-5, atol=1e-4)
+    one = world.render(cam, W, H, 50, spp_begin=b, spp_end=e)       # 40 GiB workspace: one pass, the same bits
+    assert np.array_equal(one, acc)
+    small = acc.reshape(54, 40, 96, 40, 3).mean(axis=(1, 3)) / spp
+    o, _ = orc.OracleWorld(world).render(cam.with_sample_rate(32), 96, 54, 50, 7, nthreads=16)
+    o = o / 32
+    assert abs(small.mean() - o.mean()) < 0.01 * o.mean()
+    assert np.sqrt(np.mean((small - o) ** 2)) < 0.05
 
 
 # ------------------------------------------------------------------ the C++ host mirror and the two examples

@@ -120,3 +120,10 @@ def test_sample_range(rt):
         assert all(r[k][1] == r[k + 1][0] for k in range(ws - 1))
         sizes = [e - b for b, e in r]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_square_from_points_is_rejected(rt):
+    """Square::from_points' tri0-first rule (object.rs:169-174,192) has no device counterpart: refused, not guessed."""
+    import pytest
+    with pytest.raises(NotImplementedError):
+        rt.Square.from_points((0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0.5))
