@@ -102,6 +102,9 @@ def main():
     if os.environ.get("CFTRT_GRID"):
         g = os.environ["CFTRT_GRID"].split(",")                # "mode[,cells_per_prim]"; 0: the plain lists, for profiling
         dev.set_grid(int(g[0]), float(g[1]) if len(g) > 1 else 0.0)
+    if os.environ.get("CFTRT_FINISH"):
+        f = os.environ["CFTRT_FINISH"].split(",")              # "on[,below]": deep levels path by path (profiling)
+        dev.set_finish(int(f[0]), int(f[1]) if len(f) > 1 else 0)
     scene.commit(dev)
     accum = torch.zeros(H * W * 3, dtype=torch.float32, device=f"cuda:{local_rank}")
     spp_begin, spp_end = rank * spp, (rank + 1) * spp

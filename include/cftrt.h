@@ -143,6 +143,16 @@ int cftrt_ctx_set_wave_cull(cftrt_ctx* ctx, int on);
  *   than 4096 primitives;  2: every ray walks.
  *   cells_per_prim > 0 sets the grid resolution for scenes committed afterwards (default 1); <= 0 keeps it. */
 int cftrt_ctx_set_grid(cftrt_ctx* ctx, int mode, double cells_per_prim);
+/* Sharded appends (default on): a trace level with >= 2^22 rays appends its survivors through 8 counters into a
+ * queue of 8 compacted segments instead of one counter (a single word takes ~88 returning atomics per microsecond
+ * chip-wide, one per 256 rays).  The image does not depend on the order of the queue: same image bit for bit; the
+ * switch exists for that comparison and for profiling. */
+int cftrt_ctx_set_shards(cftrt_ctx* ctx, int on);
+/* Deep levels path by path (default on): once fewer than `below` rays are alive (0 keeps the current value,
+ * default 2^20; the host looks every 4 levels) the remaining trace levels run in one launch in which every lane
+ * follows one path to its end (k_trace_finish) instead of one launch per level.  Same image bit for bit; the switch
+ * exists for that comparison and for profiling.  Scenes with PhongModel materials always run level by level. */
+int cftrt_ctx_set_finish(cftrt_ctx* ctx, int on, uint32_t below);
 /* Intersect-kernel variant: rays per lane of k_intersect / k_trace_level (1..4); 0 = the tuned default. */
 int cftrt_ctx_set_variant(cftrt_ctx* ctx, int variant);
 

@@ -365,6 +365,14 @@ class Device:
         of scenes committed afterwards.  Images are identical with any mode."""
         self.check(self.lib.cftrt_ctx_set_grid(self.h, int(mode), float(cells_per_prim)))
 
+    def set_shards(self, on):
+        """Big trace levels append through 8 counters into a segmented queue (default on); same image either way."""
+        self.check(self.lib.cftrt_ctx_set_shards(self.h, int(bool(on))))
+
+    def set_finish(self, on, below=0):
+        """Deep trace levels path by path in one launch (default on, below 2^20 live rays); same image either way."""
+        self.check(self.lib.cftrt_ctx_set_finish(self.h, int(bool(on)), int(below)))
+
     def set_variant(self, v):
         self.check(self.lib.cftrt_ctx_set_variant(self.h, int(v)))
 

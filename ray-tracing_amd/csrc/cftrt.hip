@@ -27,6 +27,9 @@ struct cftrt_ctx {
   int grid = 1;           // uniform grid (an extension to the reference's linear scan): 0 off, 1 waves the cone cull does not serve, 2 every wave
   double grid_density = 1.;   // cells per primitive the grid is sized for (scenes committed afterwards)
   int split = 0;          // 0: fused k_trace_level per level (default); 1: k_intersect -> hit records -> k_shade
+  int shards = 1;         // 1: levels with >= 2^22 rays append through CFT_SHARDS counters into a segmented queue
+  int finish = 1;         // 1: once few rays are alive the remaining levels run path by path in one launch (k_trace_finish)
+  uint32_t finish_below = 1u << 20;
   int n_cu = 256;
   // grow-only workspace
   DevBuf qa[2], qb[2], qc[2], h0[2], h1[2], ht[2], rad, pqa, pqb, pqc, pqd, counts, accum_tmp, misc;
@@ -157,7 +160,7 @@ int cftrt_ctx_create(int device, cftrt_ctx** out) {
   hipEventCreate(&ctx->ev_t1);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
-  if ((e = hipHostMalloc((void**)&ctx->host_counts, (2 * CFTRT_MAX_LEVELS + 8) * sizeof(uint32_t))) != hipSuccess) {
+  if ((e = hipHostMalloc((void**)&ctx->host_counts, (size_t)CFT_SHARDS * CFT_SHARD_STRIDE * sizeof(uint32_t))) != hipSuccess) {
     g_create_error = std::string("hipHostMalloc: ") + hipGetErrorString(e);
     hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -211,6 +214,19 @@ int cftrt_ctx_set_pipeline(cftrt_ctx* ctx, int split) {
   if (!ctx) return CFTRT_ERR_INVALID;
   if (split != 0 && split != 1) return fail(ctx, CFTRT_ERR_INVALID, "pipeline must be 0 (fused) or 1 (split)");
   ctx->split = split;
+  return CFTRT_OK;
+}
+
+int cftrt_ctx_set_shards(cftrt_ctx* ctx, int on) {
+  if (!ctx) return CFTRT_ERR_INVALID;
+  ctx->shards = on ? 1 : 0;
+  return CFTRT_OK;
+}
+
+int cftrt_ctx_set_finish(cftrt_ctx* ctx, int on, uint32_t below) {
+  if (!ctx) return CFTRT_ERR_INVALID;
+  ctx->finish = on ? 1 : 0;
+  if (below) ctx->finish_below = below;
   return CFTRT_OK;
 }
 
@@ -485,7 +501,7 @@ int cftrt_scene_commit(cftrt_scene* s) {
   // grid_walk_ray).  Cubic cells sized for ~1 cell per primitive (measured optimum 0.5 .. 2), at most 128 per axis; every primitive is
   // registered in the cells its bound, inflated by 1e-3 of the box half-extent, overlaps.  Scenes with fewer than 64
   // such primitives, or whose primitives are large against any sensible cell (a Cornell box), get no grid.
-  std::vector<uint4> gridCell;
+  std::vector<uint2> gridCell;   // per cell: (first sphere entry << 8) | count, (first triangle entry << 8) | count
   std::vector<float4> gridSph;
   std::vector<float2> gridSphX;
   std::vector<uint32_t> gridTri;
@@ -559,22 +575,30 @@ int cftrt_scene_commit(cftrt_scene* s) {
         };
         for (int i = 0; i < nP; ++i) if (in_grid(i)) each_cell(i, [&](size_t c) { (i < nS + nM ? cntS : cntT)[c]++; total++; });
         if (total > 24 * (size_t)nG) continue;   // primitives much larger than the cells: coarser
+        {   // the packed record holds 8 bits of count and 24 of offset
+          uint32_t cmax = 0;
+          size_t tS = 0, tT = 0;
+          for (size_t c = 0; c < nc; ++c) { cmax = std::max(cmax, std::max(cntS[c], cntT[c])); tS += cntS[c]; tT += cntT[c]; }
+          if (cmax > 255u) continue;
+          if (tS >= (1u << 24) || tT >= (1u << 24)) break;   // (no grid: lists)
+        }
         gridCell.resize(nc);
+        std::vector<uint32_t> offS(nc), offT(nc);
         uint32_t oS = 0, oT = 0;
-        for (size_t c = 0; c < nc; ++c) { gridCell[c] = make_uint4(oS, 0, oT, 0); oS += cntS[c]; oT += cntT[c]; }
+        for (size_t c = 0; c < nc; ++c) { offS[c] = oS; offT[c] = oT; gridCell[c] = make_uint2(oS << 8, oT << 8); oS += cntS[c]; oT += cntT[c]; }
         gridSph.resize((size_t)oS);
         gridSphX.resize((size_t)oS);
         gridTri.resize(oT);
         for (int i = 0; i < nP; ++i)
           if (in_grid(i)) each_cell(i, [&](size_t c) {
             if (i < nS + nM) {
-              const size_t e = (size_t)gridCell[c].x + gridCell[c].y++;
+              const size_t e = (size_t)offS[c] + (gridCell[c].x++ & 255u);
               float ib;
               memcpy(&ib, &i, 4);
               gridSph[e] = i < nS ? sphF[i] : msphB[i - nS];
               gridSphX[e] = make_float2(i < nS ? sphR2[i] : 0.f, ib);
             } else {
-              gridTri[(size_t)gridCell[c].z + gridCell[c].w++] = (uint32_t)(i - nS - nM);
+              gridTri[(size_t)offT[c] + (gridCell[c].y++ & 255u)] = (uint32_t)(i - nS - nM);
             }
           });
         for (int k = 0; k < 3; ++k) { G.n[k] = n[k]; G.lo[k] = blo[k]; G.hi[k] = bhi[k]; G.cs[k] = cs[k]; }
@@ -583,7 +607,7 @@ int cftrt_scene_commit(cftrt_scene* s) {
     }
     if (gridSph.empty()) { gridSph.push_back(make_float4(0.f, 0.f, 0.f, 0.f)); gridSphX.push_back(make_float2(0.f, 0.f)); }
     if (gridTri.empty()) gridTri.push_back(0u);
-    if (gridCell.empty()) gridCell.push_back(make_uint4(0, 0, 0, 0));
+    if (gridCell.empty()) gridCell.push_back(make_uint2(0, 0));
   }
   std::vector<MatDev> mats(nm);
   int n_phong = 0;
@@ -617,6 +641,31 @@ int cftrt_scene_commit(cftrt_scene* s) {
   if ((rc = upload(s, gridSph, &D.gridSph))) return rc;
   if ((rc = upload(s, gridSphX, &D.gridSphX))) return rc;
   if ((rc = upload(s, gridTri, &D.gridTri))) return rc;
+  {   // list-ordered copies for the exact evaluation of candidates (scene_dev.h)
+    std::vector<double> lsD(4 * sphF_gid.size()), lmD(8 * msph_gid.size());
+    std::vector<int4> listRec;
+    for (size_t i = 0; i < sphF_gid.size(); ++i) memcpy(&lsD[4 * i], &sphD[4 * (size_t)sphF_gid[i]], 32);
+    for (size_t i = 0; i < msph_gid.size(); ++i) {
+      memcpy(&lmD[8 * i], &sphD[4 * (size_t)msph_gid[i]], 32);
+      memcpy(&lmD[8 * i + 4], &s->sph_mv[3 * (size_t)msph_gid[i]], 24);
+      lmD[8 * i + 7] = 0.;
+    }
+    for (const std::vector<int>* v : {&sphF_gid, &msph_gid, &triF_gid, &mtri_gid})
+      for (int g : *v) listRec.push_back(make_int4(g, prim_obj[g], prim_mat[g], 0));
+    if ((rc = upload(s, lsD, &D.lsD))) return rc;
+    if ((rc = upload(s, lmD, &D.lmD))) return rc;
+    if ((rc = upload(s, listRec, &D.listRec))) return rc;
+    D.prec_g0 = -1;
+    if (!prec_gid.empty()) {
+      const int g = prec_gid[0];
+      const double* mv = &s->sph_mv[3 * (size_t)g];
+      if (mv[0] == 0. && mv[1] == 0. && mv[2] == 0.) {
+        D.prec_g0 = g; D.prec_mat0 = prim_mat[g];
+        D.prec_c0x = sphD[4 * (size_t)g]; D.prec_c0y = sphD[4 * (size_t)g + 1]; D.prec_c0z = sphD[4 * (size_t)g + 2];
+        D.prec_r0 = sphD[4 * (size_t)g + 3];
+      }
+    }
+  }
   if ((rc = upload(s, sphD, &D.sphD))) return rc;
   if ((rc = upload(s, s->sph_mv, &D.sphMvD))) return rc;
   if ((rc = upload(s, s->tri_p, &D.triD))) return rc;
@@ -770,10 +819,15 @@ static void launch_intersect(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, cons
 }
 
 // k_trace_level<R, NS>: the fused pipeline's one launch per level (same R / NS choice as launch_intersect).
+// gen != null (level 0): the launch generates the primary rays itself (no k_generate).
 static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, uint32_t* counts, uint32_t level,
                                uint32_t max_depth, uint64_t pid_base, uint32_t k0, uint32_t k1, bool two_scans,
                                uint32_t role0, uint32_t role1, QueueDev qout, float4* rad, PhongQueueDev pq,
-                               uint32_t* phong_counts, uint32_t* xstats, uint32_t P) {
+                               uint32_t* phong_counts, uint32_t* xstats, uint32_t P, const GenArgs* gen, uint32_t in_D,
+                               uint32_t* out_D_io) {
+  // *out_D_io on entry: nonzero = the caller wants the output queue sharded; on return: the segment stride used (0: dense)
+  const bool want_shards = *out_D_io != 0;
+  *out_D_io = 0;
   int R = ctx->variant ? ctx->variant : CFT_RAYS_PER_LANE;
   if (!ctx->variant && P < (1u << 20)) R = 2;
   if (two_scans && R > 2) R = 2;
@@ -783,7 +837,7 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
   // measured on S500: 2^18 .. 2^20 within 1 % on the lists; with the grid the level kernel stays ahead down to ~2^17
   const uint32_t tail_below = S.grid_mode ? 1u << 17 : 1u << 19;
   // (with the grid no wave scans a whole list; short lists are still quicker split over the four waves)
-  if (!ctx->variant && P < tail_below && (!S.grid_mode || S.n_sphF + S.n_msph + S.n_triF <= 2048)) {
+  if (!gen && !in_D && !ctx->variant && P < tail_below && (!S.grid_mode || S.n_sphF + S.n_msph + S.n_triF <= 2048)) {
     // too few rays to fill the chip: the list is split over the 4 waves of a block (k_trace_tail), 128 rays per block
     uint64_t blocks = ((uint64_t)P + 127) / 128;
     blocks = std::max<uint64_t>(1, std::min<uint64_t>(blocks, (uint64_t)ctx->n_cu * 8));
@@ -797,9 +851,25 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
     return;
   }
   const uint32_t g = grid_for(ctx, ((uint64_t)P + R - 1) / R, 8);
-#define CFT_LAUNCH(RR, NN, LL) hipLaunchKernelGGL((k_trace_level<RR, NN, LL>), dim3(g), dim3(CFT_BLOCK), 0, st, S, q, counts, \
-                                                  level, max_depth, pid_base, k0, k1, role0, role1, qout, rad, pq,            \
-                                                  phong_counts, xstats)
+  const GenArgs no_gen{};
+  // sharded output: trips of this launch <= ceil(P / 64 R) + one partial trip per input segment; segment `it mod 8`
+  // receives the survivors of every 8th trip
+  uint32_t out_k = 1, out_D = 0;
+  if (want_shards) {
+    const uint64_t trips = ((uint64_t)P + 64u * R - 1) / (64u * R) + CFT_SHARDS;
+    out_k = CFT_SHARDS;
+    out_D = (uint32_t)((trips + CFT_SHARDS - 1) / CFT_SHARDS) * 64u * R;
+    *out_D_io = out_D;
+  }
+#define CFT_LAUNCH(RR, NN, LL)                                                                                              \
+  do {                                                                                                                      \
+    if (gen) hipLaunchKernelGGL((k_trace_level<RR, NN, LL, true>), dim3(g), dim3(CFT_BLOCK), 0, st, S, q, counts, level,     \
+                                max_depth, pid_base, k0, k1, role0, role1, qout, rad, pq, phong_counts, xstats, *gen, in_D,  \
+                                out_k, out_D);                                                                              \
+    else hipLaunchKernelGGL((k_trace_level<RR, NN, LL, false>), dim3(g), dim3(CFT_BLOCK), 0, st, S, q, counts, level,        \
+                            max_depth, pid_base, k0, k1, role0, role1, qout, rad, pq, phong_counts, xstats, no_gen, in_D,   \
+                            out_k, out_D);                                                                                  \
+  } while (0)
 #define CFT_LAUNCH_R(LL)                                                    \
   if (two_scans) {                                                        \
     if (R == 1) CFT_LAUNCH(1, 2, (LL) | 3); else CFT_LAUNCH(2, 2, (LL) | 3);  \
@@ -871,6 +941,7 @@ struct EvTimer {
   }
 };
 
+static const size_t kQueueSlack = (size_t)CFT_SHARDS * 2 * 64 * 4 + 256;   // slots a sharded queue may need beyond the ray count
 // Device buffers of one pass (P paths): the ray queues, the radiance slots, the Phong queue, the level counters.
 struct PassBufs {
   QueueDev q[2];
@@ -879,7 +950,12 @@ struct PassBufs {
   float4* rad;
   uint32_t* counts;
 };
-static const size_t kCountWords = 2 * CFTRT_MAX_LEVELS + 8;   // [0..L] level counts, [L+1..2L] phong counts, then misc
+static const size_t kShardWords = 2 * CFTRT_MAX_LEVELS + 8 + 128 + 2;   // used words of shard 0's block
+static_assert(kShardWords <= CFT_SHARD_STRIDE, "shard 0's counters, statistics and stamps must fit its block");
+static const size_t kCountWords = (size_t)CFT_SHARDS * CFT_SHARD_STRIDE;   // shard s of level l: word s * CFT_SHARD_STRIDE + l; the rest in shard 0's block:   // (+ 64 stamp sums of 64 bits of the diagnostic build)
+static const size_t kStampWord = 2 * CFTRT_MAX_LEVELS + 2 + 8;   // even: 8-byte aligned behind a 256-byte aligned base
+static_assert(kStampWord % 2 == 0, "stamp sums are 64-bit words");   // [0..L] level counts, [L+1..2L+1] phong counts, then: second evaluations, rescans, k_trace_finish's queue cursor
+static_assert(CFTRT_MAX_LEVELS == CFTRT_MAX_LEVELS_DEV, "kernels.h and cftrt.h disagree on the level limit");
 
 static uint64_t bytes_per_path(const cftrt_ctx* ctx, const SceneDev& S) {
   const bool two_scans = S.any_motion && S.n_lights > 0;
@@ -891,10 +967,11 @@ static int bufs_from_ctx(cftrt_ctx* ctx, const SceneDev& S, uint32_t P, PassBufs
   const bool phong = S.n_phong_mats > 0;
   const bool two_scans = S.any_motion && S.n_lights > 0;
   int rc;
+  const size_t Q = (size_t)P + kQueueSlack;   // a sharded queue: CFT_SHARDS segments, each rounded up to whole trips
   for (int k = 0; k < 2; ++k) {
-    if ((rc = ensure(ctx, ctx->qa[k], (size_t)P * 16))) return rc;
-    if ((rc = ensure(ctx, ctx->qb[k], (size_t)P * 16))) return rc;
-    if ((rc = ensure(ctx, ctx->qc[k], (size_t)P * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->qa[k], Q * 16))) return rc;
+    if ((rc = ensure(ctx, ctx->qb[k], Q * 16))) return rc;
+    if ((rc = ensure(ctx, ctx->qc[k], Q * 8))) return rc;
   }
   for (int k = 0; ctx->split && k < (two_scans ? 2 : 1); ++k) {   // hit records: split pipeline only
     if ((rc = ensure(ctx, ctx->h0[k], (size_t)P * 16))) return rc;
@@ -920,7 +997,7 @@ static int bufs_from_ctx(cftrt_ctx* ctx, const SceneDev& S, uint32_t P, PassBufs
 
 // Carved out of the static array (`base` = its device address on the ctx's device, from hipGetSymbolAddress).
 // No allocation; fails if the pass does not fit.
-static const size_t kStaticHeader = 4096;   // the counters, and room for the 256-byte alignment of each carve
+static const size_t kStaticHeader = kCountWords * 4 + 2 * kQueueSlack * 40 + 4096;   // the counters, the queues' slack, and room for the 256-byte alignment of each carve
 static int bufs_from_static(cftrt_ctx* ctx, const SceneDev& S, uint32_t P, PassBufs* B) {
   const bool phong = S.n_phong_mats > 0;
   const bool two_scans = S.any_motion && S.n_lights > 0;
@@ -935,10 +1012,11 @@ static int bufs_from_static(cftrt_ctx* ctx, const SceneDev& S, uint32_t P, PassB
     return p;
   };
   B->counts = (uint32_t*)carve(kCountWords * 4);
+  const size_t Q = (size_t)P + kQueueSlack;
   for (int k = 0; k < 2; ++k) {
-    B->q[k].a = (float4*)carve((size_t)P * 16);
-    B->q[k].b = (float4*)carve((size_t)P * 16);
-    B->q[k].c = (float2*)carve((size_t)P * 8);
+    B->q[k].a = (float4*)carve(Q * 16);
+    B->q[k].b = (float4*)carve(Q * 16);
+    B->q[k].c = (float2*)carve(Q * 8);
   }
   B->rad = (float4*)carve((size_t)P * 16);
   B->hA = B->hB = HitDev{nullptr, nullptr, nullptr};
@@ -983,13 +1061,17 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
   PhongQueueDev pq = B.pq;
   float4* rad = B.rad;
 
-  if (tm.begin(CLS_GEN)) return fail(ctx, CFTRT_ERR_HIP, "hipEventCreate failed");
   const int tiled = (C.width % 32u == 0 && C.height % 8u == 0 && npix == C.width * C.height && P % npix == 0 && pid_base % npix == 0) ? 1 : 0;
-  hipLaunchKernelGGL(k_generate, dim3(grid_for(ctx, P, 16)), dim3(CFT_BLOCK), 0, st_, C, pid_base, P, k0, k1, jitter, tiled, q[0]);
-  tm.end();
+  const GenArgs gen{C, jitter, tiled};
+  if (ctx->split) {   // the fused pipeline generates inside its level-0 launch
+    if (tm.begin(CLS_GEN)) return fail(ctx, CFTRT_ERR_HIP, "hipEventCreate failed");
+    hipLaunchKernelGGL(k_generate, dim3(grid_for(ctx, P, 16)), dim3(CFT_BLOCK), 0, st_, C, pid_base, P, k0, k1, jitter, tiled, q[0]);
+    tm.end();
+  }
 
   uint32_t ub = P;   // upper bound on the live rays of the current level (a ray spawns at most one ray)
   uint32_t levels_run = 0;
+  uint32_t in_D = 0;   // segment stride of the current level's input queue (0: dense)
   // Motion key of the lights' `looked` scan: the reference scans once per light that looks (SkyLight, LightShape),
   // keyed here by that light's index in world.lights (Point/Parallel lights never scan, light.rs:17-19).  With
   // several such lights the scans share the first one's key (known deviations).
@@ -1001,9 +1083,12 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
     int in = level & 1, outq = in ^ 1;
     const uint32_t nl = (uint32_t)S.n_lights;
     if (!ctx->split) {
-      tm.begin(CLS_ISECT);   // the fused kernel is booked as the intersect class (ms_shade stays 0)
+      if (tm.begin(CLS_ISECT)) return fail(ctx, CFTRT_ERR_HIP, "hipEventCreate failed");   // booked as the intersect class (ms_shade stays 0)
+      // big levels append through CFT_SHARDS counters (one counter takes ~88 appends per microsecond)
+      uint32_t out_D = (ctx->shards && ub >= (1u << 22) && level + 1 < max_depth) ? 1u : 0u;
       launch_trace_level(ctx, S, q[in], counts, level, max_depth, pid_base, k0, k1, two_scans, two_scans ? looked_role : nl, nl,
-                         q[outq], rad, pq, phong_counts, xstats, ub);
+                         q[outq], rad, pq, phong_counts, xstats, ub, level == 0 ? &gen : nullptr, in_D, &out_D);
+      in_D = out_D;
       tm.end();
     } else {
       tm.begin(CLS_ISECT);
@@ -1025,10 +1110,27 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
     // next level's count; stop when the queue has drained
     if ((level & (ub < (1u << 19) ? 15u : 3u)) == 3u && level + 1 < max_depth) {
       tm.flush();
-      HIP_TRY(ctx, hipMemcpyAsync(ctx->host_counts, counts + level + 1, 4, hipMemcpyDeviceToHost, st_));
+      // (one word per shard of the next level's count)
+      HIP_TRY(ctx, hipMemcpy2DAsync(ctx->host_counts, 4, counts + level + 1, CFT_SHARD_STRIDE * 4, 4, CFT_SHARDS, hipMemcpyDeviceToHost, st_));
       HIP_TRY(ctx, hipStreamSynchronize(st_));
+      {
+        uint64_t live = 0;
+        for (int sh = 0; sh < CFT_SHARDS; ++sh) live += ctx->host_counts[sh];
+        ctx->host_counts[0] = (uint32_t)live;
+      }
       if (ctx->host_counts[0] == 0) break;
       ub = ctx->host_counts[0];
+      if (!ctx->split && !phong && ctx->finish && !ctx->variant && ub < ctx->finish_below) {
+        // few rays left: every remaining level in ONE launch, path by path (k_trace_finish); one lane per live ray,
+        // at most what the chip holds at once (lanes refill from the queue)
+        if (tm.begin(CLS_ISECT)) return fail(ctx, CFTRT_ERR_HIP, "hipEventCreate failed");
+        const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)ub + CFT_BLOCK - 1) / CFT_BLOCK, (uint64_t)ctx->n_cu * 8));
+        hipLaunchKernelGGL(k_trace_finish, dim3(blocks), dim3(CFT_BLOCK), 0, st_, S, q[outq], counts, level + 1, max_depth,
+                           pid_base, k0, k1, two_scans ? looked_role : nl, nl, two_scans ? 1 : 0, rad, xstats + 2, xstats, in_D);
+        tm.end();
+        levels_run = max_depth;
+        break;
+      }
     }
   }
   if (accum_dev) {
@@ -1044,6 +1146,7 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
     const uint32_t* hc = ctx->host_counts;
     const uint32_t* hp = hc + CFTRT_MAX_LEVELS + 1;
     for (uint32_t l = 0; l < levels_run && l < CFTRT_MAX_LEVELS; ++l) {
+      for (int sh = 1; sh < CFT_SHARDS; ++sh) ctx->host_counts[l] += ctx->host_counts[sh * CFT_SHARD_STRIDE + l];
       st->rays_per_level[l] += hc[l];
       st->rays += hc[l];
       uint64_t pr = (uint64_t)hp[l] * (uint64_t)S.n_lights;
@@ -1051,6 +1154,21 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
       st->rays += pr;
       if (hc[l] && l + 1 > st->levels) st->levels = l + 1;
     }
+#ifdef CFT_STAMPS
+    if (getenv("CFTRT_STAMPS")) {
+      static const char* names[8] = {"gen", "sort", "setup", "scan", "park", "epilogue", "append", "other"};
+      for (uint32_t l = 0; l < 8 && l < levels_run; ++l) {
+        const unsigned long long* sp = (const unsigned long long*)(hc + kStampWord) + 8 * l;
+        unsigned long long tot = 0;
+        for (int p = 0; p < 8; ++p) tot += sp[p];
+        if (!tot) continue;
+        const double trips = (double)hc[l] / 256.0;   // (R = 4)
+        fprintf(stderr, "stamps level %u (%u rays): total %.0f cycles per 256 rays |", l, hc[l], (double)tot / trips);
+        for (int p = 0; p < 8; ++p) fprintf(stderr, " %s %.1f%%", names[p], 100.0 * (double)sp[p] / (double)tot);
+        fprintf(stderr, "\n");
+      }
+    }
+#endif
     st->exact_second += hc[2 * CFTRT_MAX_LEVELS + 2];
     st->exact_rescan += hc[2 * CFTRT_MAX_LEVELS + 3];
     st->paths += P;

@@ -23,10 +23,14 @@ __device__ __forceinline__ f3 cross3(f3 a, f3 b) {
 __device__ __forceinline__ f3 madd3(f3 a, f3 b, float s) {
   return f3{fmaf(b.x, s, a.x), fmaf(b.y, s, a.y), fmaf(b.z, s, a.z)};
 }
-__device__ __forceinline__ f3 unit3(f3 a) {  // util.rs:48-50 (v / len); IEEE sqrt + divide
-  float l = sqrtf(dot3(a, a));
-  float inv = 1.0f / l;
-  return a * inv;
+// util.rs:48-50 (v / len).  1 / len is the hardware reciprocal square root (1 ulp) refined by one Newton step, so the
+// result is unit to ~1 ulp like the IEEE sqrt + divide form, at a quarter of its instructions (the shading runs in
+// f32 against an f64 reference either way; the cull's error model allows directions that are unit to a few ulp).
+__device__ __forceinline__ f3 unit3(f3 a) {
+  const float x = dot3(a, a);
+  float y = __builtin_amdgcn_rsqf(x);
+  y = y * fmaf(-0.5f * x, y * y, 1.5f);
+  return a * y;
 }
 
 // ---- Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11), counter = (pid_lo, pid_hi, level, purpose)
@@ -67,21 +71,20 @@ __host__ __device__ __forceinline__ float motion_time(uint32_t scan_word, uint32
   return u24f(lowbias32(scan_word ^ (obj * 0x9E3779B9u)));
 }
 
-// util.rs:384-395 — on the sphere surface, z >= 0, not uniform (reproduced as is)
+// util.rs:384-395 — on the sphere surface, z >= 0, not uniform (reproduced as is): theta = 2 pi u_theta,
+// phi = pi u_phi - pi/2.  The angles are multiples of pi of exact f32 numbers, so sin / cos come from sincospi (exact
+// range reduction, no large-argument path): sin(phi) = -cos(pi u_phi), cos(phi) = sin(pi u_phi).
 __device__ __forceinline__ f3 gen_point_in_sphere(float radius, float u_theta, float u_phi) {
-  const float PI_F = 3.14159265358979323846f;
-  float theta = (2.0f * PI_F) * u_theta;
-  float phi = fmaf(PI_F, u_phi, -0.5f * PI_F);
-  float st, ct, sp, cp;
-  sincosf(theta, &st, &ct);
-  sincosf(phi, &sp, &cp);
+  float st, ct, s1, c1;
+  sincospif(2.0f * u_theta, &st, &ct);
+  sincospif(u_phi, &s1, &c1);
+  const float sp = -c1, cp = s1;
   return f3{radius * sp * ct, radius * sp * st, radius * cp};
 }
 // util.rs:397-402 — half disk
 __device__ __forceinline__ void gen_point_in_disk(float radius, float u_theta, float u_r, float* x, float* y) {
-  const float PI_F = 3.14159265358979323846f;
   float st, ct;
-  sincosf(PI_F * u_theta, &st, &ct);
+  sincospif(u_theta, &st, &ct);
   float k = radius * u_r;
   *x = k * ct;
   *y = k * st;

@@ -28,6 +28,7 @@
 #include "scene_dev.h"
 
 #define CFT_BLOCK 256
+#define CFTRT_MAX_LEVELS_DEV 256   // = CFTRT_MAX_LEVELS of include/cftrt.h (static_assert in cftrt.hip)
 #define CFT_SHADE_CHUNK 1024
 #ifndef CFT_SHADE_UNROLL
 #define CFT_SHADE_UNROLL 4   // ray sub-batches of a chunk in flight together (loads overlap)
@@ -35,6 +36,31 @@
 #ifndef CFT_RAYS_PER_LANE
 #define CFT_RAYS_PER_LANE 4
 #endif
+
+// Diagnostic build (-DCFT_STAMPS, never the shipped library): shader-clock stamps around the phases of a
+// k_trace_level trip, summed per wave and added to 64-bit words behind the level counters (phase p of level l < 8 at
+// stats + 8 + 2 (8 l + p)); CFTRT_STAMPS=1 makes the host print them.  Stamp values reach no output.
+#ifdef CFT_STAMPS
+#define CFT_STAMP_DECL uint64_t st_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t st_last_ = __builtin_amdgcn_s_memtime()
+#define CFT_STAMP(p) do { const uint64_t now_ = __builtin_amdgcn_s_memtime(); st_acc_[p] += now_ - st_last_; st_last_ = now_; } while (0)
+#define CFT_STAMP_FLUSH(stats, level)                                                                   \
+  do {                                                                                                  \
+    if ((level) < 8u && (threadIdx.x & 63u) == 0u)                                                      \
+      for (int p_ = 0; p_ < 8; ++p_)                                                                    \
+        atomicAdd((unsigned long long*)((stats) + 8 + 2 * (8 * (level) + p_)), (unsigned long long)st_acc_[p_]); \
+  } while (0)
+#else
+#define CFT_STAMP_DECL
+#define CFT_STAMP(p)
+#define CFT_STAMP_FLUSH(stats, level)
+#endif
+
+// The ray queue of a level may come in CFT_SHARDS compacted segments (segment s at slots [s D, s D + count[s])), each
+// with its own append counter: one returning atomic per wave trip on ONE word saturates near 88 per microsecond
+// chip-wide, which capped the big levels (S500 level 0: 518 k trips in 5.7 ms).  Counter s of level l is word
+// counts[s * CFT_SHARD_STRIDE + l]; a dense queue is the case where only segment 0 is filled.
+#define CFT_SHARDS 8
+#define CFT_SHARD_STRIDE 1024   // words between the counter blocks of two shards (separate cache lines and channels)
 
 // constant-address-space views: a wave-uniform index then compiles to s_load (SGPR operands)
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -68,8 +94,14 @@ __device__ __forceinline__ bool exact_sphere(d3 o, d3 d, d3 c, double r, double*
   d3 oc = o - c;
   double b = 2. * ddot(oc, d);
   double cc = dlen2(oc) - r * r;
-  double delta = b * b - 4. * a * cc;
+  const double bb = b * b;
+  double delta = bb - 4. * a * cc;
   if (delta < 0.) return false;
+  // Origin outside (cc > 0) and moving away (b > 0): both roots are negative and the reference returns None at its
+  // `t2 < 0` test.  Decided here, before the square root and the division, whenever the rounded arithmetic cannot
+  // turn -b + sqrt(delta) into 0: delta at least 1e-11 relative below b^2 puts sqrt(delta) strictly below b.  (Half
+  // of all bounce rays leave the ground sphere upwards; a quarter of the primary rays look at the sky.)
+  if (b > 0. && cc > 0. && delta < bb * 0.99999999999) return false;
   double sq = sqrt(delta);
   // The reference divides both roots by 2a and tests the quotients' signs; 2a > 0, so the signs are the
   // numerators' (a quotient could only differ by underflowing to -0, which needs |numerator| < 2^-1021) and only
@@ -479,8 +511,8 @@ __device__ __forceinline__ Bundle wave_bundle(const RayPack<R, NS>& P) {
   }
   B.cth = cmin - 4e-6f;                      // directions are unit to a few ulp
   B.narrow = B.cth > 0.8f;
-  B.sth = sqrtf(fmaxf(1.0f - B.cth * B.cth, 0.0f)) * 1.0001f + 1e-6f;
-  B.rho = sqrtf(d2max) * 1.0001f;
+  B.sth = __builtin_amdgcn_sqrtf(fmaxf(1.0f - B.cth * B.cth, 0.0f)) * 1.0001f + 1e-6f;   // (1-ulp square roots: the slack is 1e-4)
+  B.rho = __builtin_amdgcn_sqrtf(d2max) * 1.0001f;
   return B;
 }
 
@@ -489,10 +521,10 @@ __device__ __forceinline__ bool bundle_reaches(const Bundle& B, float cx, float 
   const float vx = cx - B.rox, vy = cy - B.roy, vz = cz - B.roz;
   const float L2 = fmaf(vz, vz, fmaf(vy, vy, vx * vx));
   const float va = fmaf(vz, B.az, fmaf(vy, B.ay, vx * B.ax));
-  const float slack = 1e-5f * (1.0f + sqrtf(L2));
+  const float slack = 1e-5f * (1.0f + __builtin_amdgcn_sqrtf(L2));   // (1-ulp square roots here: far inside the slack)
   const float Rp = (r + B.rho) * 1.001f + slack;
   const float h2 = fmaf(-Rp, Rp, L2);
-  return h2 <= 0.0f || va >= B.cth * sqrtf(fmaxf(h2, 0.0f)) - B.sth * Rp - slack;
+  return h2 <= 0.0f || va >= B.cth * __builtin_amdgcn_sqrtf(fmaxf(h2, 0.0f)) - B.sth * Rp - slack;
 }
 
 template <int R, int NS>
@@ -503,7 +535,7 @@ __device__ __forceinline__ void scan_spheres_culled(const SceneDev& S, RayPack<R
     bool pass = false;
     if (idx < hi) {
       const float4 sp = S.sphF[idx];
-      pass = bundle_reaches(B, -0.5f * sp.x, -0.5f * sp.y, -0.5f * sp.z, 0.25f * sqrtf(S.sphR2[idx]));
+      pass = bundle_reaches(B, -0.5f * sp.x, -0.5f * sp.y, -0.5f * sp.z, 0.25f * __builtin_amdgcn_sqrtf(S.sphR2[idx]));
     }
     unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
     if (m) {   // walk the set bits; the next sphere's scalar loads are in flight while the current one is tested
@@ -628,10 +660,25 @@ __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>&
 #pragma unroll
   for (int k = 0; k < NS; ++k) hi[k] = inf;
   float tstop = inf;   // lower bound on the distance of every primitive the walk did not meet
-  const uint4* cells = S.gridCell;
+  // Cell record: one dword per kind, (first entry << 8) | count.  The walk runs one cell AHEAD of the tests: the step
+  // to the next cell does not depend on what the current cell holds, so the next record is requested before the
+  // current cell's entries are tested and its latency hides under them (a wave has one ray per lane in flight and a
+  // SIMD four such waves: the dependent record -> entries loads were what the walk waited for).
+  const uint2* cells = S.gridCell;
+  uint2 cell = cells[__umul24(__umul24((uint32_t)cz, (uint32_t)S.gny) + (uint32_t)cy, (uint32_t)S.gnx) + (uint32_t)cx];   // < 2^21
   while (true) {
-    const uint4 cell = cells[__umul24(__umul24((uint32_t)cz, (uint32_t)S.gny) + (uint32_t)cy, (uint32_t)S.gnx) + (uint32_t)cx];   // < 2^21
-    for (uint32_t e = cell.x, ee = cell.x + cell.y; e < ee; ++e) {
+    const float tnr = fminf(tmx, fminf(tmy, tmz));   // exit of this cell, from p
+    // step into the neighbour across the nearest plane (straight-line: three-way branches diverge)
+    {
+      const bool ax = tmx <= tmy && tmx <= tmz, ay = !ax && tmy <= tmz, az = !ax && !ay;
+      cx += ax ? stx : 0; cy += ay ? sty : 0; cz += az ? stz : 0;
+      tmx += ax ? fabsf(sdx) : 0.0f; tmy += ay ? fabsf(sdy) : 0.0f; tmz += az ? fabsf(sdz) : 0.0f;
+    }
+    const bool inside = (unsigned)cx < (unsigned)S.gnx && (unsigned)cy < (unsigned)S.gny && (unsigned)cz < (unsigned)S.gnz;
+    uint2 next = make_uint2(0u, 0u);
+    if (inside && tnr <= tendr)
+      next = cells[__umul24(__umul24((uint32_t)cz, (uint32_t)S.gny) + (uint32_t)cy, (uint32_t)S.gnx) + (uint32_t)cx];
+    for (uint32_t e = cell.x >> 8, ee = (cell.x >> 8) + (cell.x & 255u); e < ee; ++e) {
       const float4 a = S.gridSph[e];   // one 16 B load per test: divergent loads are what the walk is bound by
       // the per-ray cull of scan_sphere, unpacked (same operations in the same order): q = 2 oc.d, pass iff the
       // LINE meets the sphere.  Two cheap rejects keep lanes out of the (divergent) candidate path:
@@ -658,7 +705,7 @@ __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>&
       }
     }
     if (LISTS & 2) {
-      for (uint32_t e = cell.z, ee = cell.z + cell.w; e < ee; ++e) {
+      for (uint32_t e = cell.y >> 8, ee = (cell.y >> 8) + (cell.y & 255u); e < ee; ++e) {
         const int s = (int)S.gridTri[e];
         const float4 p0 = S.triF[3 * s], e1 = S.triF[3 * s + 1], e2 = S.triF[3 * s + 2];
         float thi = inf;
@@ -673,7 +720,6 @@ __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>&
         }
       }
     }
-    const float tnr = fminf(tmx, fminf(tmy, tmz));   // exit of this cell, from p
     if (!(tnr <= tendr)) break;                      // out of the box or beyond U: nothing left that could win
     const float tn = t0 + tnr;
     float best = hi[0];
@@ -685,11 +731,8 @@ __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>&
       tstop = guard < 0 ? 0.0f : tcut;
       break;
     }
-    // step into the neighbour across the nearest plane (straight-line: three-way branches diverge)
-    const bool ax = tmx <= tmy && tmx <= tmz, ay = !ax && tmy <= tmz, az = !ax && !ay;
-    cx += ax ? stx : 0; cy += ay ? sty : 0; cz += az ? stz : 0;
-    tmx += ax ? fabsf(sdx) : 0.0f; tmy += ay ? fabsf(sdy) : 0.0f; tmz += az ? fabsf(sdz) : 0.0f;
-    if ((unsigned)cx >= (unsigned)S.gnx || (unsigned)cy >= (unsigned)S.gny || (unsigned)cz >= (unsigned)S.gnz) break;
+    if (!inside) break;
+    cell = next;
   }
 #pragma unroll
   for (int k = 0; k < NS; ++k) P.c[k][r].lo3 = fminf(P.c[k][r].lo3, tstop);
@@ -828,9 +871,9 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P,
         bool pass = false;
         if (idx < n) {
           const float4 c0 = S.msphF[2 * idx], mv = S.msphF[2 * idx + 1];
-          const float hm = 0.5f * sqrtf(fmaf(mv.z, mv.z, fmaf(mv.y, mv.y, mv.x * mv.x))) * 1.0001f;
+          const float hm = 0.5f * __builtin_amdgcn_sqrtf(fmaf(mv.z, mv.z, fmaf(mv.y, mv.y, mv.x * mv.x))) * 1.0001f;
           pass = bundle_reaches(B, fmaf(0.5f, mv.x, c0.x), fmaf(0.5f, mv.y, c0.y), fmaf(0.5f, mv.z, c0.z),
-                                sqrtf(c0.w) * 1.0001f + hm);
+                                __builtin_amdgcn_sqrtf(c0.w) * 1.0001f + hm);
         }
         unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
         while (m) {
@@ -884,7 +927,7 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P,
           const float r0 = fmaf(gz, gz, fmaf(gy, gy, gx * gx));
           const float r1 = fmaf(e1.z - gz, e1.z - gz, fmaf(e1.y - gy, e1.y - gy, (e1.x - gx) * (e1.x - gx)));
           const float r2 = fmaf(e2.z - gz, e2.z - gz, fmaf(e2.y - gy, e2.y - gy, (e2.x - gx) * (e2.x - gx)));
-          pass = bundle_reaches(B, p0.x + gx, p0.y + gy, p0.z + gz, sqrtf(fmaxf(r0, fmaxf(r1, r2))) * 1.001f);
+          pass = bundle_reaches(B, p0.x + gx, p0.y + gy, p0.z + gz, __builtin_amdgcn_sqrtf(fmaxf(r0, fmaxf(r1, r2))) * 1.001f);
         }
         unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
         while (m) {
@@ -957,30 +1000,71 @@ __device__ __forceinline__ void ray_setup(const SceneDev& S, RayPack<R, NS>& P, 
   P.U[r] = (pre.g >= 0) ? fmaf(fabsf(u), CFT_U4EPS, u) + 1e-30f : __builtin_inff();
 }
 
+// The winner of a ray as the shading needs it.  geom: the primitive is a sphere whose centre (at this scan's motion time)
+// and radius are at hand, and mat is its material row - no further table look-up by prim id.
+struct Winner {
+  double t;    // exact distance, +inf on a miss
+  int g;       // global prim id, -1 on a miss
+  int obj;     // owning object (valid with geom; tie-breaks)
+  int mat;
+  bool geom;
+  d3 c;
+  double rad;
+};
+
+// Exact test of LIST entry li (what the f32 scan hands over) for this ray and scan: the same arithmetic as exact_prim
+// on the same numbers, fetched by list index in one round of loads (data and record together).
+__device__ __forceinline__ bool exact_list_prim(const SceneDev& S, int li, d3 o, d3 d, uint32_t scan_word, double* t_out,
+                                                Winner* w) {
+  const int4 rec = S.listRec[li];
+  w->g = rec.x; w->obj = rec.y; w->mat = rec.z;
+  w->geom = false;
+  if (li < S.n_sphF) {
+    const double* sp = S.lsD + 4 * (size_t)li;
+    w->c = ld3(sp); w->rad = sp[3];
+    w->geom = true;
+    return exact_sphere(o, d, w->c, w->rad, t_out);
+  }
+  if (li < S.n_sphF + S.n_msph) {
+    const double* sp = S.lmD + 8 * (size_t)(li - S.n_sphF);
+    d3 c = ld3(sp);
+    const d3 mv = ld3(sp + 4);
+    const double tm = (double)motion_time(scan_word, (uint32_t)rec.y);
+    c = c + mv * tm;
+    w->c = c; w->rad = sp[3];
+    w->geom = true;
+    return exact_sphere(o, d, c, w->rad, t_out);
+  }
+  return exact_prim(S, rec.x, o, d, scan_word, t_out);   // triangles: by prim id
+}
+
 // After the scan: exact evaluation of the two best candidates, rescan if a third could still win.
-// stats[0] += second evaluations, stats[1] += rescans.
-__device__ __forceinline__ Closest ray_epilogue(const SceneDev& S, float ox, float oy, float oz, float dx, float dy,
-                                                float dz, uint32_t word, const Cand& c, Closest r, uint32_t* stats,
-                                                bool* defer = nullptr) {
+// stats[0] += second evaluations, stats[1] += rescans.  pre_obj: object id of the precise-sphere hit `r` (if any).
+__device__ __forceinline__ Winner ray_epilogue_w(const SceneDev& S, float ox, float oy, float oz, float dx, float dy,
+                                                 float dz, uint32_t word, const Cand& c, Closest pre, uint32_t* stats,
+                                                 bool* defer) {
   d3 o = d3{(double)ox, (double)oy, (double)oz};
   d3 d = d3{(double)dx, (double)dy, (double)dz};
+  Winner r;
+  r.t = pre.t; r.g = pre.g; r.obj = -1; r.mat = 0; r.geom = false;
+  r.c = d3{0., 0., 0.}; r.rad = 0.;
+  auto obj_of = [&](const Winner& w) { return w.obj >= 0 ? w.obj : S.prim_obj[w.g]; };   // (only on exact ties)
   if (c.i1 >= 0) {
-    int g = list_to_gid(S, c.i1);
+    Winner w;
     double t;
-    if (exact_prim(S, g, o, d, word, &t) &&
-        (r.g < 0 || t < r.t || (t == r.t && S.prim_obj[g] < S.prim_obj[r.g]))) { r.t = t; r.g = g; }
+    if (exact_list_prim(S, c.i1, o, d, word, &t, &w) &&
+        (r.g < 0 || t < r.t || (t == r.t && w.obj < obj_of(r)))) { r = w; r.t = t; }
   }
   const bool second = c.i2 >= 0 && (double)c.lo2 <= r.t;
   if (second) {
-    int g = list_to_gid(S, c.i2);
+    Winner w;
     double t;
-    if (exact_prim(S, g, o, d, word, &t) &&
-        (r.g < 0 || t < r.t || (t == r.t && S.prim_obj[g] < S.prim_obj[r.g]))) { r.t = t; r.g = g; }
+    if (exact_list_prim(S, c.i2, o, d, word, &t, &w) &&
+        (r.g < 0 || t < r.t || (t == r.t && w.obj < obj_of(r)))) { r = w; r.t = t; }
   }
   const bool rescan = c.lo3 < __builtin_inff() && (double)c.lo3 <= r.t;   // lo3 = +inf unless a third candidate exists
-  // defer: the caller runs the rescan where the whole wave is convergent (lanes without a ray help too)
-  if (defer) *defer = rescan;
-  else exact_scan_all_wave(S, rescan, o, d, word, &r.t, &r.g);
+  // the caller runs the rescan where the whole wave is convergent (lanes without a ray help too)
+  *defer = rescan;
   if (stats) {
     unsigned long long m2 = __ballot(second), m3 = __ballot(rescan);
     if (m2 | m3) {
@@ -991,6 +1075,20 @@ __device__ __forceinline__ Closest ray_epilogue(const SceneDev& S, float ox, flo
       }
     }
   }
+  return r;
+}
+
+// The one-ray form's epilogue (parity hook, shadow rays, k_trace_finish): the winner as (t, prim id); the rescan runs
+// here, among whatever lanes are active.
+__device__ __forceinline__ Closest ray_epilogue(const SceneDev& S, float ox, float oy, float oz, float dx, float dy,
+                                                float dz, uint32_t word, const Cand& c, Closest pre, uint32_t* stats) {
+  bool rescan;
+  const Winner w = ray_epilogue_w(S, ox, oy, oz, dx, dy, dz, word, c, pre, stats, &rescan);
+  Closest r;
+  r.t = w.t; r.g = w.g;
+  const d3 o = d3{(double)ox, (double)oy, (double)oz};
+  const d3 d = d3{(double)dx, (double)dy, (double)dz};
+  exact_scan_all_wave(S, rescan, o, d, word, &r.t, &r.g);
   return r;
 }
 
@@ -1041,29 +1139,43 @@ __device__ __forceinline__ void primary_ray(const CamDev& C, uint64_t pid, uint3
   *dir = unit3(to - from);   // Ray::new normalises (ray.rs:30-35)
 }
 
+struct GenArgs {   // level-0 launches that generate their own rays (k_trace_level<.., GEN>)
+  CamDev cam;
+  int jitter, tiled;
+};
+
 // one lane = one (pixel, sample).  Queue slot i holds local path id lp (global pid = pid_base + lp).  With
 // `tiled` (whole samples of an image whose width is a multiple of 32 and height of 8) the slots of a sample run
 // through 32x8-pixel tiles, so that the 256 (or 128) consecutive slots a wave of the level kernels takes are a
 // compact pixel block: their primary rays form a narrow bundle, which the wave-level cull (wave_bundle) uses.
 // Otherwise lp = i (row-major).  The order of the queue never affects the image: radiance is stored by lp.
+__device__ __forceinline__ void generate_slot(const CamDev& C, uint64_t pid_base, uint32_t i, uint32_t k0, uint32_t k1,
+                                              int jitter, int tiled, const QueueDev& q, float4* a_out = nullptr,
+                                              float4* b_out = nullptr, uint32_t* lp_out = nullptr) {
+  uint32_t lp = i, pix = 0xFFFFFFFFu;
+  if (tiled) {   // (pid_base is a multiple of npix here, so the pixel of path pid_base + lp is lp mod npix)
+    const uint32_t npix = C.width * C.height;
+    const uint32_t smp = i / npix, j = i - smp * npix;
+    const uint32_t t = j >> 8, wi = j & 255u, ntx = C.width >> 5;
+    const uint32_t ty = t / ntx, tx = t - ty * ntx;
+    pix = (ty * 8u + (wi >> 5)) * C.width + tx * 32u + (wi & 31u);
+    lp = smp * npix + pix;
+  }
+  f3 pos, dir;
+  primary_ray(C, pid_base + lp, k0, k1, jitter, &pos, &dir, pix);
+  const float4 a = make_float4(pos.x, pos.y, pos.z, dir.x), b = make_float4(dir.y, dir.z, 1.0f, 1.0f);
+  q.a[i] = a;
+  q.b[i] = b;
+  q.c[i] = make_float2(1.0f, __uint_as_float(lp));
+  if (a_out) { *a_out = a; *b_out = b; *lp_out = lp; }
+}
+
+// Alone: the split pipeline and the parity hook.  The default pipeline generates inside the level-0 launch
+// (k_trace_level<.., GEN = true>).
 __global__ __launch_bounds__(CFT_BLOCK) void k_generate(CamDev C, uint64_t pid_base, uint32_t n, uint32_t k0,
                                                         uint32_t k1, int jitter, int tiled, QueueDev q) {
-  const uint32_t npix = C.width * C.height;
-  for (uint32_t i = blockIdx.x * CFT_BLOCK + threadIdx.x; i < n; i += gridDim.x * CFT_BLOCK) {
-    uint32_t lp = i, pix = 0xFFFFFFFFu;
-    if (tiled) {   // (pid_base is a multiple of npix here, so the pixel of path pid_base + lp is lp mod npix)
-      const uint32_t smp = i / npix, j = i - smp * npix;
-      const uint32_t t = j >> 8, wi = j & 255u, ntx = C.width >> 5;
-      const uint32_t ty = t / ntx, tx = t - ty * ntx;
-      pix = (ty * 8u + (wi >> 5)) * C.width + tx * 32u + (wi & 31u);
-      lp = smp * npix + pix;
-    }
-    f3 pos, dir;
-    primary_ray(C, pid_base + lp, k0, k1, jitter, &pos, &dir, pix);
-    q.a[i] = make_float4(pos.x, pos.y, pos.z, dir.x);
-    q.b[i] = make_float4(dir.y, dir.z, 1.0f, 1.0f);
-    q.c[i] = make_float2(1.0f, __uint_as_float(lp));
-  }
+  for (uint32_t i = blockIdx.x * CFT_BLOCK + threadIdx.x; i < n; i += gridDim.x * CFT_BLOCK)
+    generate_slot(C, pid_base, i, k0, k1, jitter, tiled, q);
 }
 
 // ------------------------------------------------------------------ intersect
@@ -1105,11 +1217,13 @@ template <int NS> struct ParkLayout {
 // Before the scan: load the lane's R rays of this level (ray i, i + stride, ...), draw the motion words, test the
 // precise spheres, fill the pack.
 // perm (optional): the queue index of each (slot, thread) when the wave has reordered its rays (wave_sort_rays).
+// gen (level 0 of the default pipeline): the ray of a slot is generated here (and written to the queue) instead of loaded.
 template <int R, int NS>
 __device__ __forceinline__ void isect_setup(const SceneDev& S, const QueueDev& q, uint32_t n, uint32_t base,
                                             uint32_t stride, uint32_t level, uint64_t pid_base, uint32_t k0,
                                             uint32_t k1, uint32_t role0, uint32_t role1, RayPack<R, NS>& P,
-                                            float (*park)[CFT_BLOCK], const uint16_t (*perm)[CFT_BLOCK] = nullptr) {
+                                            float (*park)[CFT_BLOCK], const uint16_t (*perm)[CFT_BLOCK] = nullptr,
+                                            const GenArgs* gen = nullptr) {
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     // (with perm, base is the wave's first ray)
@@ -1123,11 +1237,13 @@ __device__ __forceinline__ void isect_setup(const SceneDev& S, const QueueDev& q
       cand_init(P.c[k][r]);
     }
     if (i < n) {
-      float4 a = q.a[i];
-      float4 b = q.b[i];
+      float4 a, b;
+      uint32_t lp = 0;
+      if (gen) generate_slot(gen->cam, pid_base, i, k0, k1, gen->jitter, gen->tiled, q, &a, &b, &lp);
+      else { a = q.a[i]; b = q.b[i]; }
       ox = a.x; oy = a.y; oz = a.z; dx = a.w; dy = b.x; dz = b.y;
       if (S.any_motion) {
-        uint64_t pid = pid_base + __float_as_uint(q.c[i].y);
+        uint64_t pid = pid_base + (gen ? lp : __float_as_uint(q.c[i].y));
 #pragma unroll
         for (int k = 0; k < NS; ++k)
           P.word[k][r] = philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), level,
@@ -1170,14 +1286,15 @@ __device__ __forceinline__ void isect_park(const RayPack<R, NS>& P, float (*park
 template <int NS>
 __device__ __forceinline__ void isect_hit(const SceneDev& S, bool live, int r, int k, float ox, float oy, float oz,
                                           float dx, float dy, float dz, float (*park)[CFT_BLOCK], uint32_t* stats,
-                                          float4* h0, float4* h1, double* t64) {
+                                          float4* h0, float4* h1, double* t64, int* mat_out) {
   *h0 = make_float4(__builtin_inff(), __int_as_float(-1), 0.f, 0.f);
   *h1 = make_float4(0.f, 0.f, 0.f, 0.f);
   *t64 = __builtin_inf();
+  *mat_out = 0;
   uint32_t word = 0;
-  Closest c;
-  c.t = __builtin_inf();
-  c.g = -1;
+  Winner w;
+  w.t = __builtin_inf(); w.g = -1; w.obj = -1; w.mat = 0; w.geom = false;
+  w.c = d3{0., 0., 0.}; w.rad = 0.;
   bool rescan = false;
   if (live) {
     word = __float_as_uint(PARK(r, ParkLayout<NS>::WORD + k));
@@ -1194,17 +1311,39 @@ __device__ __forceinline__ void isect_hit(const SceneDev& S, bool live, int r, i
     cd.lo3 = PARK(r, ParkLayout<NS>::CAND + 5 * k + 2);
     cd.i1 = __float_as_int(PARK(r, ParkLayout<NS>::CAND + 5 * k + 3));
     cd.i2 = __float_as_int(PARK(r, ParkLayout<NS>::CAND + 5 * k + 4));
-    c = ray_epilogue(S, ox, oy, oz, dx, dy, dz, word, cd, pre, stats, &rescan);
+    w = ray_epilogue_w(S, ox, oy, oz, dx, dy, dz, word, cd, pre, stats, &rescan);
   }
   const d3 o = d3{(double)ox, (double)oy, (double)oz};
   const d3 d = d3{(double)dx, (double)dy, (double)dz};
-  exact_scan_all_wave(S, rescan, o, d, word, &c.t, &c.g);
-  if (live && c.g >= 0) {
-    d3 p = o + d * c.t;                        // point = pos + dir * t
-    f3 nn = hit_normal(S, c.g, p, word);
-    *h0 = make_float4((float)c.t, __int_as_float(c.g), (float)p.x, (float)p.y);
+  if (__ballot(rescan)) {
+    Closest c;
+    c.t = w.t; c.g = w.g;
+    exact_scan_all_wave_call(S, rescan, o, d, word, &c.t, &c.g);
+    if (rescan) { w.t = c.t; w.g = c.g; w.geom = false; }
+  }
+  if (live && w.g >= 0) {
+    if (!w.geom && w.g == S.prec_g0) {   // the (static) first precise sphere: its data sit in the kernel arguments
+      w.c = d3{S.prec_c0x, S.prec_c0y, S.prec_c0z};
+      w.rad = S.prec_r0; w.mat = S.prec_mat0;
+      w.geom = true;
+    }
+    const d3 p = o + d * w.t;                  // point = pos + dir * t
+    f3 nn;
+    if (w.geom) {                              // hit_normal's sphere branch on the data at hand
+      d3 n = p - w.c;
+      if (w.rad < 0.) n = d3{-n.x, -n.y, -n.z};
+      nn = mk3((float)n.x, (float)n.y, (float)n.z);
+      const float sc = fmaxf(fmaxf(fabsf(nn.x), fabsf(nn.y)), fabsf(nn.z));
+      nn = nn * __builtin_amdgcn_rcpf(sc);
+      nn = nn * __builtin_amdgcn_rsqf(dot3(nn, nn));
+      *mat_out = w.mat;
+    } else {
+      nn = hit_normal(S, w.g, p, word);
+      *mat_out = S.prim_mat[w.g];
+    }
+    *h0 = make_float4((float)w.t, __int_as_float(w.g), (float)p.x, (float)p.y);
     *h1 = make_float4((float)p.z, nn.x, nn.y, nn.z);
-    *t64 = c.t;
+    *t64 = w.t;
   }
 }
 
@@ -1243,7 +1382,8 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_intersect(SceneDev S, QueueDev q,
       for (int k = 0; k < NS; ++k) {
         float4 h0, h1;
         double t64;
-        isect_hit<NS>(S, live, r, k, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &h0, &h1, &t64);
+        int mat;
+        isect_hit<NS>(S, live, r, k, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &h0, &h1, &t64, &mat);
         if (live) {
           if (k == 0) { out0.h0[i] = h0; out0.h1[i] = h1; out0.t[i] = t64; }
           else        { out1.h0[i] = h0; out1.h1[i] = h1; out1.t[i] = t64; }
@@ -1379,7 +1519,8 @@ __device__ __forceinline__ bool shade_one(const SceneDev& S, const H& hit, f3 po
   // the material row is two dependent loads away from the prim id: start them before the lights and HitInfo::new
   const float4 B0 = hit.B0();
   const int prim = __float_as_int(B0.y);
-  const MatDev m = S.mats[prim >= 0 ? S.prim_mat[prim] : 0];
+  const int mat_row = hit.mat(S, prim);
+  const MatDev m = S.mats[mat_row];
   // ---- lights: LightSource::looked (object.rs:333-341)
   bool see = false;
   f3 col = mk3(0, 0, 0);
@@ -1449,7 +1590,7 @@ __device__ __forceinline__ bool shade_one(const SceneDev& S, const H& hit, f3 po
           pq.a[slot] = make_float4(h.p.x, h.p.y, h.p.z, h.n.x);
           pq.b[slot] = make_float4(h.n.y, h.n.z, h.dout.x, h.dout.y);
           pq.c[slot] = make_float4(h.dout.z, thr.x, thr.y, thr.z);
-          pq.d[slot] = make_uint2(lpid, (uint32_t)S.prim_mat[prim]);
+          pq.d[slot] = make_uint2(lpid, (uint32_t)mat_row);
         } break;
       }
       if (scattered) {
@@ -1467,6 +1608,7 @@ struct HitFromRecords {   // the split pipeline: hit records written by k_inters
   HitDev A, B;
   uint32_t i;
   __device__ __forceinline__ double tA() const { return A.t[i]; }
+  __device__ __forceinline__ int mat(const SceneDev& S, int prim) const { return prim >= 0 ? S.prim_mat[prim] : 0; }
   __device__ __forceinline__ float4 A0() const { return A.h0[i]; }
   __device__ __forceinline__ float4 B0() const { return B.h0[i]; }
   __device__ __forceinline__ float4 B1() const { return B.h1[i]; }
@@ -1474,7 +1616,9 @@ struct HitFromRecords {   // the split pipeline: hit records written by k_inters
 struct HitInRegisters {   // the fused pipeline
   float4 a0, b0, b1;
   double ta;   // exact distance of the lights' `looked` scan
+  int mat_id;  // material row of trace's own hit (0 on a miss)
   __device__ __forceinline__ double tA() const { return ta; }
+  __device__ __forceinline__ int mat(const SceneDev&, int) const { return mat_id; }
   __device__ __forceinline__ float4 A0() const { return a0; }
   __device__ __forceinline__ float4 B0() const { return b0; }
   __device__ __forceinline__ float4 B1() const { return b1; }
@@ -1620,29 +1764,65 @@ __device__ __forceinline__ void wave_sort_rays(const SceneDev& S, const QueueDev
 // ballot + prefix popcount order them inside the wave and ONE global atomic per wave and loop trip (R x 64 rays)
 // reserves their slots - 4x fewer atomics than one per wave and ray row, below the ~88/us a single counter
 // sustains.
-template <int R, int NS, int LISTS>
+// GEN (level 0 only): the launch also is Camera::emit_rays - isect_setup generates the primary ray of each slot instead
+// of loading it, and writes it to the queue (the 40 B a separate k_generate would write) for the slot loop after the
+// scan to read back; the writes drain under the scan.  A wave that sorts its rays first (long-list scenes, where the
+// primary rays walk the grid too) generates them into the queue before the sort and loads them like any other level.
+template <int R, int NS, int LISTS, bool GEN = false>
 __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(SceneDev S, QueueDev q, uint32_t* counts, uint32_t level,
                                                            uint32_t max_depth, uint64_t pid_base, uint32_t k0,
                                                            uint32_t k1, uint32_t role0, uint32_t role1, QueueDev qout,
                                                            float4* radiance, PhongQueueDev pq, uint32_t* phong_counts,
-                                                           uint32_t* stats) {
+                                                           uint32_t* stats, GenArgs gen, uint32_t in_D, uint32_t out_k,
+                                                           uint32_t out_D) {
   __shared__ float park[ParkLayout<NS>::WORDS * R][CFT_BLOCK];
   // (the 4-ray instances serve the primary rays, which are not sorted; their park already fills the 40 KB a block
   // may take at 4 blocks per CU)
   constexpr bool SORT = (LISTS & 4) != 0 && NS == 1;   // (two-scan instances: measured slower, they spill)
   __shared__ SortStore<R, SORT> ss;
-  const uint32_t n = counts[level];
+  // The input queue: CFT_SHARDS segments of stride in_D (a dense queue: segment 0 only).  A trip takes 64 R slots of
+  // ONE segment; trips are numbered through the segments in turn.  The survivors of trip `it` go to output segment
+  // it mod out_k (out_k = 1: dense), which therefore receives at most ceil(trips / out_k) * 64 R rays <= out_D.
+  uint32_t trips_to[CFT_SHARDS + 1];
+  trips_to[0] = 0u;
+#pragma unroll
+  for (int sh = 0; sh < CFT_SHARDS; ++sh)
+    trips_to[sh + 1] = trips_to[sh] + (AS_CONST(const uint32_t __attribute__((address_space(4)))*, counts)[sh * CFT_SHARD_STRIDE + level] + 64u * R - 1u) / (64u * R);
   const uint32_t stride = 64u;   // wave-contiguous slots, wave-uniform trip count (see k_intersect)
-  const uint32_t wstep = gridDim.x * CFT_BLOCK * R;
   const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t q_in_D = in_D;
+  const QueueDev q_all = q;
+  uint32_t n = 0;   // slots of the current trip's segment
   // bounce rays that will walk the grid are sorted by walk length inside the wave (primary rays take the cone cull)
   const bool sorted = SORT && S.grid_mode && (level > 0 || S.grid_mode == 2);
   auto slot_index = [&](int r, uint32_t base) -> uint32_t {
     if constexpr (SORT) return ss.perm[r][threadIdx.x] == 0xFFFFu ? 0xFFFFFFFFu : base - (threadIdx.x & 63u) + ss.perm[r][threadIdx.x];
     else return base + r * 64u < n ? base + r * 64u : 0xFFFFFFFFu;
   };
-  for (uint32_t wb = (blockIdx.x * CFT_BLOCK + (threadIdx.x & ~63u)) * R; wb < n; wb += wstep) {
+  CFT_STAMP_DECL;
+  for (uint32_t it = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (CFT_BLOCK / 64u) + (threadIdx.x >> 6)));
+       it < trips_to[CFT_SHARDS]; it += gridDim.x * (CFT_BLOCK / 64u)) {
+    uint32_t seg = 0;
+#pragma unroll
+    for (int sh = 1; sh < CFT_SHARDS; ++sh) seg += it >= trips_to[sh] ? 1u : 0u;
+    uint32_t seg_trip0 = 0;
+#pragma unroll
+    for (int sh = 1; sh < CFT_SHARDS; ++sh) seg_trip0 = seg == (uint32_t)sh ? trips_to[sh] : seg_trip0;
+    n = AS_CONST(const uint32_t __attribute__((address_space(4)))*, counts)[seg * CFT_SHARD_STRIDE + level];
+    const size_t qoff = (size_t)seg * q_in_D;
+    q = QueueDev{q_all.a + qoff, q_all.b + qoff, q_all.c + qoff};   // the segment, indexed from 0
+    const uint32_t wb = (it - seg_trip0) * 64u * R;
     const uint32_t base = wb + lane;
+    CFT_STAMP(7);   // (loop overhead, and the time before the first trip)
+    if constexpr (GEN && SORT) {
+#pragma unroll 1
+      for (int r = 0; r < R; ++r)
+        if (base + r * stride < n) generate_slot(gen.cam, pid_base, base + r * stride, k0, k1, gen.jitter, gen.tiled, q);
+      // the wave reads its slots back in sorted order (other lanes' slots too), through the same L1
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    CFT_STAMP(0);
     if constexpr (SORT) {
       if (sorted) {
         wave_sort_rays<R>(S, q, n, base, ss.perm, ss.hist);
@@ -1651,15 +1831,19 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(SceneDev S, QueueD
         for (int r = 0; r < R; ++r) ss.perm[r][threadIdx.x] = base + r * stride < n ? (uint16_t)(lane + r * stride) : (uint16_t)0xFFFFu;
       }
     }
+    CFT_STAMP(1);
     {
       RayPack<R, NS> P;
       if constexpr (SORT) isect_setup<R, NS>(S, q, n, wb, stride, level, pid_base, k0, k1, role0, role1, P, park, ss.perm);
-      else isect_setup<R, NS>(S, q, n, base, stride, level, pid_base, k0, k1, role0, role1, P, park);
+      else isect_setup<R, NS>(S, q, n, base, stride, level, pid_base, k0, k1, role0, role1, P, park, nullptr, GEN ? &gen : nullptr);
+      CFT_STAMP(2);
       // (the instances with the walk run the bounce levels, where nearly every wave walks the grid: without the
       // cone-cull code they keep more registers; the few narrow bundles there walk too)
       scan_lists<R, NS, (LISTS & 4) == 0, (LISTS & 4) ? (LISTS | 8) : LISTS>(S, P);
+      CFT_STAMP(3);
       isect_park<R, NS>(P, park);
     }
+    CFT_STAMP(4);
     uint32_t alive_bits = 0;
     // the slot's ray is re-read from the queue (HBM: the queue is far bigger than the caches); the next slot's
     // loads are issued before this slot is processed
@@ -1679,11 +1863,11 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(SceneDev S, QueueD
         an = q.a[j]; bn = q.b[j]; cn = q.c[j];
       }
       HitInRegisters hit;
-      isect_hit<NS>(S, live, r, 0, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.a0, &hit.b1, &hit.ta);
+      isect_hit<NS>(S, live, r, 0, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.a0, &hit.b1, &hit.ta, &hit.mat_id);
       hit.b0 = hit.a0;
       if (NS == 2) {
         double tb;
-        isect_hit<NS>(S, live, r, 1, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.b0, &hit.b1, &tb);
+        isect_hit<NS>(S, live, r, 1, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.b0, &hit.b1, &tb, &hit.mat_id);
       }
       f3 thr = mk3(b.z, b.w, c.x), npos, ndir;
       const bool alive = live && shade_one(S, hit, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), &thr, __float_as_uint(c.y), level,
@@ -1695,6 +1879,7 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(SceneDev S, QueueD
         PARK(r, 8) = thr.z;
       }
     }
+    CFT_STAMP(5);
     // append the wave's survivors: slot by slot, lanes in order
     uint32_t total = 0;
 #pragma unroll
@@ -1702,8 +1887,9 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(SceneDev S, QueueD
     if (total) {   // wave-uniform
       const uint32_t leader = (uint32_t)__ffsll((long long)__ballot(1)) - 1u;
       uint32_t wbase = 0;
-      if (lane == leader) wbase = atomicAdd(&counts[level + 1], total);
-      wbase = __shfl(wbase, (int)leader);
+      const uint32_t oseg = out_k > 1u ? it % out_k : 0u;
+      if (lane == leader) wbase = atomicAdd(&counts[oseg * CFT_SHARD_STRIDE + level + 1], total);
+      wbase = __shfl(wbase, (int)leader) + oseg * out_D;
 #pragma unroll 1
       for (int r = 0; r < R; ++r) {
         const unsigned long long m = __ballot((alive_bits >> r) & 1u);
@@ -1716,7 +1902,9 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(SceneDev S, QueueD
         wbase += (uint32_t)__popcll(m);
       }
     }
+    CFT_STAMP(6);
   }
+  CFT_STAMP_FLUSH(stats, level);
 }
 
 // The same level step for launches that cannot fill the chip (the deep levels: 16 k - 300 k live rays against
@@ -1786,11 +1974,11 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_tail(SceneDev S, QueueDe
       const float4 b = q.b[live ? i : wb];
       const float2 c = q.c[live ? i : wb];
       HitInRegisters hit;
-      isect_hit<NS>(S, live, r, 0, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.a0, &hit.b1, &hit.ta);
+      isect_hit<NS>(S, live, r, 0, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.a0, &hit.b1, &hit.ta, &hit.mat_id);
       hit.b0 = hit.a0;
       if (NS == 2) {
         double tb;
-        isect_hit<NS>(S, live, r, 1, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.b0, &hit.b1, &tb);
+        isect_hit<NS>(S, live, r, 1, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.b0, &hit.b1, &tb, &hit.mat_id);
       }
       f3 thr = mk3(b.z, b.w, c.x), npos, ndir;
       const bool alive = live && shade_one(S, hit, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), &thr, __float_as_uint(c.y), level,
@@ -1823,6 +2011,103 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_tail(SceneDev S, QueueDe
       }
     }
   }
+}
+
+// The last levels of a pass, PATH by path.  Once few rays are alive (the host switches below ~2^20) a launch per level
+// no longer fills the chip: each costs one wave's latency through setup, scan, exact evaluation and shading, whatever
+// the ray count (S500: 38 launches of 29-74 us for 0.3 % of the rays).  Here a lane keeps one path in registers and
+// follows it level after level - closest_hit (the one-ray form: grid walk or lists), World::trace's shading, next
+// ray - with no queue, no append and no launch in between; a lane whose path ends takes the next ray of the input
+// queue (one atomic per wave and refill), so the launch lasts as long as the queue feeds the lanes plus one longest
+// path.  Every hit goes through the same exact evaluation and the same shade_one as in the level kernels: the image
+// is the same bit for bit (cftrt_ctx_set_finish toggles it; tested).
+// Rays traced per level are counted in LDS and added to counts[level] at the end (counts[level0] is already right).
+// Not for scenes with PhongModel materials (their hits go through k_shadow level by level).
+__global__ __launch_bounds__(CFT_BLOCK) void k_trace_finish(SceneDev S, QueueDev q, uint32_t* counts, uint32_t level0,
+                                                            uint32_t max_depth, uint64_t pid_base, uint32_t k0, uint32_t k1,
+                                                            uint32_t role0, uint32_t role1, int two_scans, float4* radiance,
+                                                            uint32_t* cursor, uint32_t* stats, uint32_t in_D) {
+  __shared__ uint32_t hist[CFT_BLOCK / 64][CFTRT_MAX_LEVELS_DEV];
+  // the input queue may be sharded: slot v of the concatenated segments sits at seg * in_D + (v - slots before seg)
+  uint32_t slots_to[CFT_SHARDS + 1];
+  slots_to[0] = 0u;
+#pragma unroll
+  for (int sh = 0; sh < CFT_SHARDS; ++sh) slots_to[sh + 1] = slots_to[sh] + counts[sh * CFT_SHARD_STRIDE + level0];
+  const uint32_t n = slots_to[CFT_SHARDS];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  for (uint32_t l = lane; l < CFTRT_MAX_LEVELS_DEV; l += 64u) hist[wave][l] = 0u;
+  __builtin_amdgcn_wave_barrier();
+  bool have = false, drained = false;
+  f3 pos = mk3(0, 0, 0), dir = mk3(0, 0, 1), thr = mk3(0, 0, 0);
+  uint32_t lpid = 0, level = level0;
+  const PhongQueueDev no_pq{nullptr, nullptr, nullptr, nullptr};
+  while (true) {
+    if (!drained) {   // wave-uniform
+      const unsigned long long idle = __ballot(!have);
+      if (idle) {
+        const uint32_t cnt = (uint32_t)__popcll(idle);
+        uint32_t base = 0;
+        if (lane == (uint32_t)__builtin_ctzll(idle)) base = atomicAdd(cursor, cnt);
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(idle));
+        if (!have) {
+          const uint32_t v = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+          if (v < n) {
+            uint32_t i = v;
+#pragma unroll
+            for (int sh = 1; sh < CFT_SHARDS; ++sh) i += v >= slots_to[sh] ? in_D - (slots_to[sh] - slots_to[sh - 1]) : 0u;
+            const float4 a = q.a[i], b = q.b[i];
+            const float2 c = q.c[i];
+            pos = mk3(a.x, a.y, a.z); dir = mk3(a.w, b.x, b.y); thr = mk3(b.z, b.w, c.x);
+            lpid = __float_as_uint(c.y);
+            level = level0;
+            have = true;
+          }
+        }
+        drained = base + cnt >= n;
+      }
+    }
+    if (!__ballot(have)) break;   // the queue is empty and every path of this wave has ended
+    if (have) {
+      // rays per level: one LDS add per distinct level among the wave's paths (refilled lanes lag behind the others)
+      for (unsigned long long todo = __ballot(1); todo;) {
+        const int lead = (int)__builtin_ctzll(todo);
+        const uint32_t lv = (uint32_t)__builtin_amdgcn_readlane((int)level, lead);
+        const unsigned long long m = __ballot(level == lv);
+        if (lane == (uint32_t)lead) hist[wave][lv] += (uint32_t)__popcll(m);
+        todo &= ~m;
+      }
+      uint32_t wA = 0, wB = 0;
+      if (S.any_motion) {
+        const uint64_t pid = pid_base + lpid;
+        wA = philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), level, CFT_PURPOSE_SCAN0 + role0, k0, k1).x;
+        wB = two_scans ? philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), level, CFT_PURPOSE_SCAN0 + role1, k0, k1).x : wA;
+      }
+      const Closest cA = closest_hit(S, pos.x, pos.y, pos.z, dir.x, dir.y, dir.z, wA, stats);
+      Closest cB = cA;
+      if (two_scans) cB = closest_hit(S, pos.x, pos.y, pos.z, dir.x, dir.y, dir.z, wB, stats);
+      HitInRegisters hit;
+      hit.ta = cA.t;
+      hit.a0 = make_float4((float)cA.t, __int_as_float(cA.g), 0.f, 0.f);
+      hit.b0 = make_float4(__builtin_inff(), __int_as_float(-1), 0.f, 0.f);
+      hit.b1 = make_float4(0.f, 0.f, 0.f, 0.f);
+      hit.mat_id = cB.g >= 0 ? S.prim_mat[cB.g] : 0;
+      if (cB.g >= 0) {   // the hit record as isect_hit builds it
+        const d3 o = d3{(double)pos.x, (double)pos.y, (double)pos.z};
+        const d3 d = d3{(double)dir.x, (double)dir.y, (double)dir.z};
+        const d3 p = o + d * cB.t;
+        const f3 nn = hit_normal(S, cB.g, p, wB);
+        hit.b0 = make_float4((float)cB.t, __int_as_float(cB.g), (float)p.x, (float)p.y);
+        hit.b1 = make_float4((float)p.z, nn.x, nn.y, nn.z);
+      }
+      f3 npos, ndir;
+      have = shade_one(S, hit, pos, dir, &thr, lpid, level, max_depth, pid_base, k0, k1, radiance, no_pq, nullptr, &npos, &ndir);
+      pos = npos; dir = ndir;
+      level += 1;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t l = lane; l < CFTRT_MAX_LEVELS_DEV; l += 64u)
+    if (l > level0 && hist[wave][l]) atomicAdd(&counts[l], hist[wave][l]);
 }
 
 // ------------------------------------------------------------------ shadow (PhongModel::render)

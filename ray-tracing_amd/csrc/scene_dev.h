@@ -42,7 +42,7 @@ struct SceneDev {
   const int* mtri_gid;
   int n_mtri;
   // ---- uniform grid over the lists above (an extension; 0 cells = none).  Cell (x, y, z) -> gridCell[(z*gny + y)*gnx + x]
-  const uint4* gridCell;  // (first sphere entry, count, first triangle entry, count)
+  const uint2* gridCell;  // (sphere entries, triangle entries), each (first entry << 8) | count
   const float4* gridSph;  // per entry: the sphF / msphB entry
   const float2* gridSphX; // per entry: (16 r^2, list index bits), read when the cull passes
   const uint32_t* gridTri;   // index into triF
@@ -59,6 +59,14 @@ struct SceneDev {
   const double* triD;     // n_tri x 9: p0, p1, p2
   const double* triMvD;   // n_tri x 3
   int n_tri;
+  // ---- the listed primitives again, in LIST order (index = what the f32 scan hands over), so that the exact evaluation of
+  // a candidate starts with one round of loads instead of list index -> prim id -> data -> material id:
+  const double* lsD;      // static list spheres, 4 each: cx, cy, cz, r
+  const double* lmD;      // moving list spheres, 8 each: cx, cy, cz, r, mvx, mvy, mvz, -
+  const int4* listRec;    // every list entry [sphF | msph | triF | mtri]: (global prim id, object id, material id, -)
+  // the first precise sphere, in the kernel arguments themselves (the ground of scene.rs wins most rays)
+  double prec_c0x, prec_c0y, prec_c0z, prec_r0;
+  int prec_g0, prec_mat0;   // prec_g0 = -1: none, or it moves
   // ---- per-prim tables ----
   const int* prim_obj;
   const int* prim_mat;

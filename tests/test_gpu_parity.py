@@ -622,6 +622,54 @@ def test_grid_random_scenes(rt, seed, cells):
         assert list(out[0][1].rays_per_level[: int(out[0][1].levels)]) == list(out[mode][1].rays_per_level[: int(out[mode][1].levels)])
 
 
+@pytest.mark.parametrize("name,W,H,spp,depth", [("s500", 640, 360, 4, 50), ("scene_rs", 320, 200, 4, 10), ("cornell", 160, 120, 8, 10),
+                                                 ("s20k", 320, 184, 2, 12), ("random", 256, 128, 4, 12)])
+def test_finish_kernel_is_exact(rt, name, W, H, spp, depth):
+    """The deep levels run path by path in one launch (k_trace_finish) once few rays are alive.  Same hits, same
+    shading: with it off (one launch per level to the end), on at the default threshold and on from the first look
+    at the counts (level 4), the image and the rays per level must be equal bit for bit.  scene_rs covers the two
+    scans per level (motion + sky), cornell a scene without grid, random moving spheres and triangles."""
+    world, cam = (_random_world(rt, 2) if name == "random" else
+                  getattr(rt.scenes, {"s500": "s500", "scene_rs": "scene_rs", "cornell": "cornell_rs", "s20k": "s20k"}[name])())
+    dev = rt.default_device()
+    out = []
+    try:
+        for on, below in ((0, 0), (1, 1 << 20), (1, 0xFFFFFFFF)):
+            dev.set_finish(on, below)
+            out.append(world.render(cam, W, H, depth, spp_begin=0, spp_end=spp, return_stats=True))
+    finally:
+        dev.set_finish(1, 1 << 20)
+    for acc, st in out[1:]:
+        assert np.array_equal(out[0][0], acc)
+        assert int(st.rays) == int(out[0][1].rays) and int(st.levels) == int(out[0][1].levels)
+        assert list(st.rays_per_level[:depth]) == list(out[0][1].rays_per_level[:depth])
+        assert int(st.exact_second) == int(out[0][1].exact_second)
+    assert int(out[2][1].launches_intersect) < int(out[0][1].launches_intersect) or depth <= 5
+
+
+@pytest.mark.parametrize("name,W,H,spp,depth", [("s500", 1920, 1080, 3, 50), ("scene_rs", 1600, 1000, 3, 10), ("s20k", 1920, 1080, 3, 6)])
+def test_sharded_append_is_exact(rt, name, W, H, spp, depth):
+    """Levels with >= 2^22 rays append through 8 counters into a queue of 8 segments.  Which slot a ray lands in never
+    matters to the image: with the shards off, on, and on with the per-path finish kernel taking over a SHARDED queue
+    (finish from the first look at the counts), the image and the rays per level are equal bit for bit."""
+    world, cam = getattr(rt.scenes, {"s500": "s500", "scene_rs": "scene_rs", "s20k": "s20k"}[name])()
+    dev = rt.default_device()
+    out = []
+    try:
+        for shards, fin_below in ((0, 1 << 20), (1, 1 << 20), (1, 0xFFFFFFFF)):
+            dev.set_shards(shards)
+            dev.set_finish(1, fin_below)
+            out.append(world.render(cam, W, H, depth, spp_begin=0, spp_end=spp, return_stats=True))
+    finally:
+        dev.set_shards(1)
+        dev.set_finish(1, 1 << 20)
+    assert int(out[0][1].paths) >= 1 << 22
+    for acc, st in out[1:]:
+        assert np.array_equal(out[0][0], acc)
+        assert list(st.rays_per_level[:depth]) == list(out[0][1].rays_per_level[:depth])
+        assert int(st.rays) == int(out[0][1].rays)
+
+
 def test_full_size_properties(rt, orc):
     """BASELINE.json configs[2] at full size (1920x1080, 64 spp, depth 50): size-independent properties."""
     world, cam = rt.scenes.s500()
