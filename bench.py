@@ -5,16 +5,17 @@ max depth 50 (BASELINE.json configs[2]), on N GPUs of one node.
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A step = one full render of the frame: generate -> [intersect -> shade]*depth -> resolve into a device
-accumulation buffer (+ for N>1 one RCCL reduce of the W*H*3 f32 image to rank 0).  Scaling is WEAK: every
-rank renders its own 64 samples per pixel (sample range [64*rank, 64*(rank+1)); the Philox stream is keyed
-by the global sample index), so the N-GPU image holds 64*N spp.  The scene is resident in HBM before the
-timed region; nothing crosses PCIe inside it.
+A step = one full render of the frame: [generate +] (intersect + shade) x depth -> resolve into a device
+accumulation buffer (+ for N>1 one RCCL reduce of the W*H*3 f32 image to rank 0).  The frame shards by SAMPLE
+RANGE (ray-tracing_amd/multi.py, the code the tests run): `--scaling weak` (default) gives every rank its own 64
+samples per pixel (the N-GPU image holds 64 N spp); `--scaling strong` splits the 64 samples of ONE frame over the
+ranks.  The Philox stream is keyed by the global sample index.  The scene is resident in HBM before the timed
+region; nothing crosses PCIe inside it.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
-import ctypes
+import glob
 import importlib
 import json
 import os
@@ -28,38 +29,85 @@ WIDTH, HEIGHT, SPP, DEPTH = 1920, 1080, 64, 50
 PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (vector)"
 
 
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
 def cpu_baseline():
-    """The CPU restatement (oracle/, kind "port") timed on this box's host cores on a bounded sample of
-    the same workload: same scene, camera, depth; 960x540 at 32 spp (1/4 of the pixels, 1/2 of the spp)."""
+    """The CPU restatement (oracle/, kind "port") timed on ALL of this process's host cores (sched_getaffinity) on a
+    bounded sample of the same workload: same scene, camera and depth at a reduced image size and sample count,
+    sized from a short probe so that the leg takes ~15 s whatever the core count."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
     rt = importlib.import_module("ray-tracing_amd")
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))
-    w, h, spp = 960, 540, 32
-    world, cam = rt.scenes.s500(width=w, height=h, spp=spp)
+    cores = host_cores()
+    w, h = 960, 540
+    world, cam = rt.scenes.s500(width=w, height=h, spp=1)
     ow = ob.OracleWorld(world)
     t0 = time.perf_counter()
-    _, rays = ow.render(cam, w, h, DEPTH, rt.scenes.SAMPLE_SEED, 0, spp, nthreads=cores)
+    _, probe_rays = ow.render(cam, w, h, DEPTH, rt.scenes.SAMPLE_SEED, 0, 1, nthreads=cores)
+    probe = time.perf_counter() - t0
+    spp = int(max(2, min(64, round(15.0 / max(probe, 1e-3)))))
+    t0 = time.perf_counter()
+    _, rays = ow.render(cam, w, h, DEPTH, rt.scenes.SAMPLE_SEED, 1, 1 + spp, nthreads=cores)
     dt = time.perf_counter() - t0
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"S500 {w}x{h} {spp}spp depth{DEPTH}: {rays} rays in {dt:.1f} s (f64 C++ restatement of "
-                      "the Rust reference, std::thread over rows)"}
+            "sample": f"S500 {w}x{h} {spp}spp depth{DEPTH}: {rays} rays in {dt:.1f} s on {cores} threads "
+                      f"(sched_getaffinity; f64 C++ restatement of the Rust reference, std::thread over rows; "
+                      f"sample count sized by a 1-spp probe of {probe:.2f} s)"}
 
 
-def hbm_traffic_per_launch(rays_per_step, launches_per_step, kernel="k_trace_level"):
-    """HBM bytes per k_intersect launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled for gfx950,
-    WRITE_SIZE as is; profiles/r01_hbm_traffic.json) scaled to this run's ray count; None if absent.
-    PMC counters cannot be read inside the timed run."""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+def committed_profile(pattern):
+    """Newest committed profile summary matching profiles/<pattern> (round-tagged names sort by round)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    if not files:
+        return None, None
     try:
-        k = json.load(open(path))["kernels"][kernel]
-    except (OSError, KeyError, ValueError):
+        return json.load(open(files[-1])), os.path.basename(files[-1])
+    except (OSError, ValueError):
+        return None, None
+
+
+def hbm_traffic_per_launch(rays_per_step, launches_per_step):
+    """HBM bytes per level-kernel launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled for gfx950,
+    WRITE_SIZE as is; scripts/hbm_traffic.py) scaled to this run's ray count; None if absent.  PMC counters cannot
+    be read inside the timed run."""
+    d, _ = committed_profile("r0*_hbm_traffic.json")
+    if not d:
         return None
-    return k["bytes_per_ray"] * rays_per_step / max(launches_per_step, 1)
+    try:
+        per_ray = sum(v["bytes_per_ray"] for k, v in d["kernels"].items() if k.startswith("k_trace"))
+    except (KeyError, TypeError):
+        return None
+    return per_ray * rays_per_step / max(launches_per_step, 1)
+
+
+def as_run_utilisation():
+    """Instruction-based utilisation of the level kernels AS RUN (wave cull, grid) from the committed SQ counter pass
+    (scripts/pmc_summary.py over `rocprofv3 --pmc SQ_*`): per kernel instance, VALU busy = SQ_ACTIVE_INST_VALU x 4 /
+    (SIMDs x cycles), lanes active per VALU instruction = SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU), and their
+    product, the share of the chip's VALU lane-cycles that did work."""
+    d, name = committed_profile("r0*_pmc_sq*.json")
+    if not d:
+        return None
+    out = {"source": "profiles/" + name, "kernels": []}
+    for e in d:
+        c = e.get("largest_dispatch", {})
+        if "k_trace" not in e.get("name", ""):
+            continue
+        try:
+            cycles = c["GRBM_GUI_ACTIVE"] / 8.0          # summed over the 8 XCDs
+            busy = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cycles)
+            lanes = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
+        except (KeyError, ZeroDivisionError):
+            continue
+        out["kernels"].append({"kernel": e["name"].replace("void ", ""), "duration_us": c.get("duration_us"),
+                               "valu_busy": busy, "lanes_active_per_valu_inst": lanes,
+                               "valu_lane_cycles_used": busy * lanes, "valu_insts": c.get("SQ_INSTS_VALU")})
+    return out if out["kernels"] else None
 
 
 def main():
@@ -67,14 +115,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: 64 spp per rank; strong: the 64 spp of one frame split over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-plain-scan", action="store_true", help="skip the untimed plain-linear-scan leg (N=1 only)")
+    ap.add_argument("--no-plain-scan", action="store_true", help="skip the plain-linear-scan leg (N=1 only)")
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--spp", type=int, default=SPP)
     args = ap.parse_args()
 
-    import torch
+    import torch   # before the product library: one HIP runtime per process
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
@@ -105,18 +155,24 @@ def main():
     if os.environ.get("CFTRT_FINISH"):
         f = os.environ["CFTRT_FINISH"].split(",")              # "on[,below]": deep levels path by path (profiling)
         dev.set_finish(int(f[0]), int(f[1]) if len(f) > 1 else 0)
+    if os.environ.get("CFTRT_SHARDS"):
+        dev.set_shards(int(os.environ["CFTRT_SHARDS"]))
     scene.commit(dev)
     accum = torch.zeros(H * W * 3, dtype=torch.float32, device=f"cuda:{local_rank}")
-    spp_begin, spp_end = rank * spp, (rank + 1) * spp
+    # the whole job's sample count: weak = spp per rank, strong = spp in all (ray-tracing_amd/multi.py cuts the range)
+    spp_total = spp * world_size if args.scaling == "weak" else spp
+    last = {}
+
+    def render_range(b, e, acc):
+        last["st"] = scene.render_device(cam, W, H, DEPTH, acc.data_ptr(), seed=rt.scenes.SAMPLE_SEED,
+                                         spp_begin=b, spp_end=e, device=dev)
 
     def step():
         accum.zero_()
-        torch.cuda.synchronize()          # the library runs on its own stream
-        st = scene.render_device(cam, W, H, DEPTH, accum.data_ptr(), seed=rt.scenes.SAMPLE_SEED,
-                                 spp_begin=spp_begin, spp_end=spp_end, device=dev)
-        if distributed:
-            dist.reduce(accum, dst=0)      # RCCL sum of the per-GPU f32 images over xGMI
-        return st
+        torch.cuda.synchronize()          # the library runs on its own stream (include/cftrt.h, "Device and stream")
+        last["st"] = None
+        rt.multi.render_sharded(render_range, spp_total, accum, dist=dist if distributed else None, dst=0)
+        return last["st"]
 
     def fence():
         torch.cuda.synchronize()
@@ -131,10 +187,13 @@ def main():
     stats = [step() for _ in range(args.steps)]
     fence()
     elapsed = time.perf_counter() - t0
+    stats = [s for s in stats if s is not None]   # (a rank with an empty sample range rendered nothing)
 
-    # Untimed extra leg at N=1: the same frame with the wave cull and the grid off, i.e. the reference's plain linear
-    # scan (every ray tests every sphere).  There the algorithmic flops are the executed ones, so this is the
-    # roofline fraction that speaks about the kernel's arithmetic; the timed region above runs the default path.
+    # N = 1 only: the same frame with the wave cull and the grid off, i.e. the reference's plain linear scan, where
+    # every ray tests every sphere and the algorithmic flops of SURVEY 8d ARE the executed ones.  This leg, timed live
+    # with the library's HIP events, is what `roofline.achieved` / `frac` report: it is the only reading in which the
+    # flop count bounds the kernel.  The headline `value` above is the default path (cull + grid), which skips most of
+    # those tests; its work-delivered figure sits beside it as `delivered_equiv`.
     plain = None
     if world_size == 1 and not args.no_plain_scan and not split:
         dev.set_grid(0)
@@ -151,10 +210,10 @@ def main():
             dev.set_wave_cull(1)
         pms = sum(x.ms_intersect for x in ps)
         pach = sum(x.flops for x in ps) / (pms * 1e-3) / 1e12
-        plain = {"achieved": pach, "frac": pach / PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                 "avg_launch_ms": pms / max(sum(int(x.launches_intersect) for x in ps), 1),
-                 "ms_per_step": dt1 / 2 * 1e3, "mrays_per_s": sum(int(x.rays) for x in ps) / dt1 / 1e6,
-                 "basis": "wave cull and grid off: every ray tests every sphere, algorithmic flops = executed flops"}
+        pl = sum(int(x.launches_intersect) for x in ps)
+        plain = {"achieved": pach, "frac": pach / PEAK_FP32_VALU_TFLOPS, "launches": pl, "avg_launch_ms": pms / max(pl, 1),
+                 "algorithmic_flops_per_launch": sum(x.flops for x in ps) / max(pl, 1),
+                 "ms_per_step": dt1 / 2 * 1e3, "mrays_per_s": sum(int(x.rays) for x in ps) / dt1 / 1e6}
 
     rays = sum(int(s.rays) for s in stats)
     t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
@@ -165,13 +224,35 @@ def main():
     elapsed_max, rays_all = float(t.item()), float(r.item())
 
     if rank == 0:
+        nst = max(len(stats), 1)
         ms_isect = sum(s.ms_intersect for s in stats)
-        # split: the scan's flops over k_intersect's time; fused: the level kernel does scan + shading, so its
-        # algorithmic work is the whole per-ray figure of SURVEY 8d (16 Nsph + 44 Ntri + 200)
         fl_isect = sum((s.flops_intersect if split else s.flops) for s in stats)
         n_launch = sum(int(s.launches_intersect) for s in stats)
-        achieved = fl_isect / (ms_isect * 1e-3) / 1e12 if ms_isect > 0 else 0.0
+        delivered = fl_isect / (ms_isect * 1e-3) / 1e12 if ms_isect > 0 else 0.0
         s0 = stats[-1]
+        kernel = "k_intersect" if split else "k_trace_level"
+        roof = {"bound": "valu_fp32", "kernel": kernel, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s"}
+        if plain:
+            roof.update({"achieved": plain["achieved"], "frac": plain["frac"], "launches": plain["launches"],
+                         "avg_launch_ms": plain["avg_launch_ms"],
+                         "algorithmic_flops_per_launch": plain["algorithmic_flops_per_launch"],
+                         "flops_per_ray": 16 * 500 + 200,
+                         "basis": "executed work: the level kernel as the reference's plain linear scan (wave cull and grid "
+                                  "off; every ray tests every sphere, so SURVEY 8d's 16 flop x 500 spheres + 200 per ray are "
+                                  "the flops executed), timed live with HIP events in an extra leg of this run "
+                                  "(plain_scan_ms_per_step); the timed `value` runs the default path, see delivered_equiv",
+                         "plain_scan_ms_per_step": plain["ms_per_step"], "plain_scan_mrays_per_s": plain["mrays_per_s"]})
+        else:
+            roof.update({"achieved": None, "frac": None,
+                         "basis": "the executed-work leg (plain linear scan) runs at N = 1 in the fused pipeline only"})
+        roof["traffic"] = hbm_traffic_per_launch(int(s0.rays), n_launch // nst)
+        roof["delivered_equiv"] = {
+            "tflops": delivered, "of_peak": delivered / PEAK_FP32_VALU_TFLOPS, "launches": n_launch,
+            "avg_launch_ms": ms_isect / max(n_launch, 1),
+            "basis": "work DELIVERED by the default path per second of its level kernels: every ray is charged the "
+                     "reference's whole scan although the wave cull and the grid skip most of it - not a utilisation, "
+                     "and not bounded by the peak"}
+        roof["as_run_utilisation"] = as_run_utilisation()
         out = {
             "metric": "Mrays/s (all bounces)",
             "value": rays_all / elapsed_max / 1e6,
@@ -181,32 +262,24 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"S500 (500 spheres, diffuse/metal/glass, SkyLight) {W}x{H} {spp}spp/GPU "
-                                   f"max depth {DEPTH} (BASELINE.json configs[2]); sample-range split over GPUs, "
-                                   "RCCL reduce of the f32 image",
+            "config": {"workload": f"S500 (500 spheres, diffuse/metal/glass, SkyLight) {W}x{H} max depth {DEPTH} "
+                                   f"(BASELINE.json configs[2]); {spp_total} spp in all = "
+                                   + (f"{spp} spp per GPU (weak)" if args.scaling == "weak" else f"{spp} spp split over the GPUs (strong)")
+                                   + "; sample-range split, RCCL reduce of the f32 image",
                        "rays_per_step_per_gpu": int(s0.rays), "paths_per_step_per_gpu": int(s0.paths),
                        "trace_levels": int(s0.levels), "exact_second_evals": int(s0.exact_second),
                        "exact_rescans": int(s0.exact_rescan)},
-            "roofline": {"bound": "valu_fp32", "kernel": "k_intersect" if split else "k_trace_level", "achieved": achieved,
-                         "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
-                         "traffic": hbm_traffic_per_launch(int(s0.rays), n_launch // max(args.steps, 1),
-                                                            "k_intersect" if split else "k_trace_level"),
-                         "launches": n_launch, "avg_launch_ms": ms_isect / max(n_launch, 1),
-                         "algorithmic_flops_per_launch": fl_isect / max(n_launch, 1),
-                         "flops_per_ray": 16 * 500 + (0 if split else 200), "whole_loop_tflops": sum(s.flops for s in stats) / elapsed_max / 1e12,
-                         "basis": "reference-equivalent: every ray is charged the reference's whole linear scan (SURVEY 8d: "
-                                  "16 flop x 500 spheres + 200); the wave cull and the grid skip most of those tests, so "
-                                  "this is work delivered, not VALU work executed - see plain_scan for the latter",
-                         "plain_scan": plain},
-            "kernel_ms_per_step": {"generate": sum(s.ms_generate for s in stats) / args.steps,
-                                   ("intersect" if split else "trace_level"): ms_isect / args.steps,
-                                   "shade": sum(s.ms_shade for s in stats) / args.steps,
-                                   "resolve": sum(s.ms_resolve for s in stats) / args.steps,
-                                   "device_total": sum(s.ms_total for s in stats) / args.steps},
+            "roofline": roof,
+            "kernel_ms_per_step": {"generate": sum(s.ms_generate for s in stats) / nst,
+                                   ("intersect" if split else "trace_level"): ms_isect / nst,
+                                   "shade": sum(s.ms_shade for s in stats) / nst,
+                                   "resolve": sum(s.ms_resolve for s in stats) / nst,
+                                   "device_total": sum(s.ms_total for s in stats) / nst,
+                                   "launches_per_step": n_launch / nst},
         }
         if world_size == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

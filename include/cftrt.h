@@ -213,6 +213,21 @@ int cftrt_render_device_static(cftrt_scene* scene, const cftrt_camera* cam, uint
                                uint32_t max_depth, uint64_t seed, void* accum_device,
                                cftrt_stats* stats);
 
+/* ---- multi-GPU: the one exchange step of the path ------------------------------------------- */
+/* The image shards by sample range: rank g renders samples [b_g, e_g) of every pixel into its own accumulation
+ * buffer (cftrt_render_device) and the buffers are summed - where the reference adds every sample into one vector
+ * under a mutex (examples/scene.rs:97).  These calls do that sum with RCCL (ncclReduce over xGMI) for hosts without
+ * torch.distributed; librccl is loaded on first use (dlopen), a single-GPU host never needs it.
+ *   rank 0: cftrt_comm_unique_id(id)  -> ship the 128 bytes to the other ranks by any host channel
+ *   every rank (one process or host thread per GPU): cftrt_comm_init(ctx, nranks, rank, id)
+ *   after the render calls: cftrt_reduce(ctx, accum_device, W*H*3, root) - in place, f32 sum into root's buffer,
+ *   on the ctx's stream (ordered behind the renders); returns after the stream has drained. */
+#define CFTRT_COMM_ID_BYTES 128
+int cftrt_comm_unique_id(unsigned char* id128);
+int cftrt_comm_init(cftrt_ctx* ctx, int nranks, int rank, const unsigned char* id128);
+int cftrt_reduce(cftrt_ctx* ctx, void* accum_device, uint64_t n_floats, int root);
+int cftrt_comm_destroy(cftrt_ctx* ctx);
+
 /* ---- parity hooks (one kernel each, host buffers) ------------------------------------------ */
 /* Camera::emit_rays for path ids [pid0, pid0+n): out_rays = n x 6 floats (pos, dir).
  * jitter = 0 disables the pixel/lens draws (pixel centre, lens centre). */

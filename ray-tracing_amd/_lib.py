@@ -74,6 +74,10 @@ SYMBOLS = [
                                       C.c_uint32, C.c_uint32, C.c_uint64, _P, C.POINTER(cftrt_stats)]),
     ("cftrt_render_device_static", C.c_int, [_P, C.POINTER(cftrt_camera), C.c_uint32, C.c_uint32, C.c_uint32,
                                              C.c_uint32, C.c_uint32, C.c_uint64, _P, C.POINTER(cftrt_stats)]),
+    ("cftrt_comm_unique_id", C.c_int, [C.POINTER(C.c_ubyte)]),
+    ("cftrt_comm_init", C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_ubyte)]),
+    ("cftrt_reduce", C.c_int, [_P, _P, C.c_uint64, C.c_int]),
+    ("cftrt_comm_destroy", C.c_int, [_P]),
     ("cftrt_generate", C.c_int, [_P, C.POINTER(cftrt_camera), C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64,
                                  C.c_uint64, C.c_int, _F]),
     ("cftrt_intersect", C.c_int, [_P, _F, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _I, _D, _F,

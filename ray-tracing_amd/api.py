@@ -373,6 +373,24 @@ class Device:
         """Deep trace levels path by path in one launch (default on, below 2^20 live rays); same image either way."""
         self.check(self.lib.cftrt_ctx_set_finish(self.h, int(bool(on)), int(below)))
 
+    # -- multi-GPU without torch.distributed: RCCL through the C ABI
+    def comm_unique_id(self):
+        buf = (C.c_ubyte * 128)()
+        rc = self.lib.cftrt_comm_unique_id(buf)
+        if rc != 0:
+            raise L.CftrtError(rc, self.lib.cftrt_last_error(None).decode())
+        return bytes(buf)
+
+    def comm_init(self, nranks, rank, unique_id):
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        self.check(self.lib.cftrt_comm_init(self.h, int(nranks), int(rank), buf))
+
+    def reduce(self, accum_ptr, n_floats, root=0):
+        self.check(self.lib.cftrt_reduce(self.h, C.c_void_p(accum_ptr), int(n_floats), int(root)))
+
+    def comm_destroy(self):
+        self.check(self.lib.cftrt_comm_destroy(self.h))
+
     def set_variant(self, v):
         self.check(self.lib.cftrt_ctx_set_variant(self.h, int(v)))
 

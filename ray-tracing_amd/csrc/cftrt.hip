@@ -3,6 +3,8 @@
 #include "../../include/cftrt.h"
 #include "kernels.h"
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -37,7 +39,42 @@ struct cftrt_ctx {
   std::vector<hipEvent_t> events;
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
   unsigned char* static_scratch = nullptr;   // this device's copy of `scratch` (cftrt_render_device_static)
+  void* comm = nullptr;                      // ncclComm_t of cftrt_comm_init (RCCL, loaded on demand)
+  int comm_ranks = 0, comm_rank = 0;
 };
+
+// RCCL through dlopen: the library is only needed by hosts that combine several GPUs without torch.distributed
+// (cftrt_comm_* / cftrt_reduce); a single-GPU host never loads it.
+struct RcclApi {
+  void* lib = nullptr;
+  struct UniqueId { char internal[128]; };
+  int (*GetUniqueId)(UniqueId*) = nullptr;
+  int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
+  int (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+static RcclApi* rccl_api(std::string* err) {
+  static RcclApi api;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (api.lib) break;
+    }
+    if (api.lib) {
+      api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
+      api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
+      api.Reduce = (decltype(api.Reduce))dlsym(api.lib, "ncclReduce");
+      api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+      api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+      if (!api.GetUniqueId || !api.CommInitRank || !api.Reduce || !api.CommDestroy) { dlclose(api.lib); api.lib = nullptr; }
+    }
+  }
+  if (!api.lib) { if (err) *err = "librccl.so.1 could not be loaded (dlopen) or lacks the nccl* entry points"; return nullptr; }
+  return &api;
+}
 
 // Workspace of the entry point that allocates nothing (cftrt_render_device_static): ray queues, radiance and level
 // counters of a pass live in this file-scope array instead of hipMalloc'ed buffers.  Every GPU the library runs on
@@ -174,6 +211,7 @@ void cftrt_ctx_destroy(cftrt_ctx* ctx) {
   if (!ctx) return;
   DeviceGuard guard(ctx->device);
   hipStreamSynchronize(ctx->stream);
+  if (ctx->comm) (void)cftrt_comm_destroy(ctx);
   DevBuf* bufs[] = {&ctx->qa[0], &ctx->qa[1], &ctx->qb[0], &ctx->qb[1], &ctx->qc[0], &ctx->qc[1], &ctx->h0[0],
                     &ctx->h0[1], &ctx->h1[0], &ctx->h1[1], &ctx->ht[0], &ctx->ht[1], &ctx->rad, &ctx->pqa, &ctx->pqb, &ctx->pqc,
                     &ctx->pqd, &ctx->counts, &ctx->accum_tmp, &ctx->misc};
@@ -1259,6 +1297,59 @@ int cftrt_render(cftrt_scene* s, const cftrt_camera* cam, uint32_t width, uint32
   if (rc) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(accum_host, ctx->accum_tmp.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return CFTRT_OK;
+}
+
+// ------------------------------------------------------------------ multi-GPU: the one exchange step
+int cftrt_comm_unique_id(unsigned char* id128) {
+  if (!id128) return CFTRT_ERR_INVALID;
+  RcclApi* R = rccl_api(&g_create_error);
+  if (!R) return CFTRT_ERR_HIP;
+  RcclApi::UniqueId id;
+  const int rc = R->GetUniqueId(&id);
+  if (rc != 0) { g_create_error = std::string("ncclGetUniqueId: ") + (R->GetErrorString ? R->GetErrorString(rc) : "error"); return CFTRT_ERR_HIP; }
+  memcpy(id128, id.internal, 128);
+  return CFTRT_OK;
+}
+
+int cftrt_comm_init(cftrt_ctx* ctx, int nranks, int rank, const unsigned char* id128) {
+  if (!ctx) return CFTRT_ERR_INVALID;
+  if (!id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, CFTRT_ERR_INVALID, "comm_init: bad rank, size or id");
+  if (ctx->comm) return fail(ctx, CFTRT_ERR_STATE, "comm_init: this ctx already has a communicator");
+  RcclApi* R = rccl_api(&ctx->err);
+  if (!R) return CFTRT_ERR_HIP;
+  DEVICE_GUARD(ctx);
+  RcclApi::UniqueId id;
+  memcpy(id.internal, id128, 128);
+  const int rc = R->CommInitRank(&ctx->comm, nranks, id, rank);
+  if (rc != 0) { ctx->comm = nullptr; ctx->err = std::string("ncclCommInitRank: ") + (R->GetErrorString ? R->GetErrorString(rc) : "error"); return CFTRT_ERR_HIP; }
+  ctx->comm_ranks = nranks; ctx->comm_rank = rank;
+  return CFTRT_OK;
+}
+
+int cftrt_reduce(cftrt_ctx* ctx, void* accum_device, uint64_t n_floats, int root) {
+  if (!ctx) return CFTRT_ERR_INVALID;
+  if (!ctx->comm) return fail(ctx, CFTRT_ERR_STATE, "reduce: no communicator (cftrt_comm_init)");
+  if (!accum_device && n_floats) return fail(ctx, CFTRT_ERR_INVALID, "reduce: null buffer");
+  if (root < 0 || root >= ctx->comm_ranks) return fail(ctx, CFTRT_ERR_INVALID, "reduce: root out of range");
+  RcclApi* R = rccl_api(&ctx->err);
+  if (!R) return CFTRT_ERR_HIP;
+  DEVICE_GUARD(ctx);
+  // in place: every rank's buffer is summed into root's (ncclFloat32 = 7, ncclSum = 0), on the ctx's stream, so it is
+  // ordered behind the render calls that filled the buffer
+  const int rc = R->Reduce(accum_device, accum_device, (size_t)n_floats, 7, 0, root, ctx->comm, ctx->stream);
+  if (rc != 0) { ctx->err = std::string("ncclReduce: ") + (R->GetErrorString ? R->GetErrorString(rc) : "error"); return CFTRT_ERR_HIP; }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return CFTRT_OK;
+}
+
+int cftrt_comm_destroy(cftrt_ctx* ctx) {
+  if (!ctx) return CFTRT_ERR_INVALID;
+  if (!ctx->comm) return CFTRT_OK;
+  RcclApi* R = rccl_api(&ctx->err);
+  if (R) { DeviceGuard guard(ctx->device); (void)R->CommDestroy(ctx->comm); }
+  ctx->comm = nullptr;
+  ctx->comm_ranks = 0;
   return CFTRT_OK;
 }
 
