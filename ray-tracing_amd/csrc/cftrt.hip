@@ -618,12 +618,12 @@ int cftrt_scene_commit(cftrt_scene* s) {
           size_t tS = 0, tT = 0;
           for (size_t c = 0; c < nc; ++c) { cmax = std::max(cmax, std::max(cntS[c], cntT[c])); tS += cntS[c]; tT += cntT[c]; }
           if (cmax > 255u) continue;
-          if (tS >= (1u << 24) || tT >= (1u << 24)) break;   // (no grid: lists)
+          if (tS >= (1u << 24) || tT >= (1u << 20)) break;   // (no grid: lists)
         }
         gridCell.resize(nc);
         std::vector<uint32_t> offS(nc), offT(nc);
         uint32_t oS = 0, oT = 0;
-        for (size_t c = 0; c < nc; ++c) { offS[c] = oS; offT[c] = oT; gridCell[c] = make_uint2(oS << 8, oT << 8); oS += cntS[c]; oT += cntT[c]; }
+        for (size_t c = 0; c < nc; ++c) { offS[c] = oS; offT[c] = oT; gridCell[c] = make_uint2(oS << 8, oT << 12); oS += cntS[c]; oT += cntT[c]; }
         gridSph.resize((size_t)oS);
         gridSphX.resize((size_t)oS);
         gridTri.resize(oT);
@@ -636,9 +636,37 @@ int cftrt_scene_commit(cftrt_scene* s) {
               gridSph[e] = i < nS ? sphF[i] : msphB[i - nS];
               gridSphX[e] = make_float2(i < nS ? sphR2[i] : 0.f, ib);
             } else {
-              gridTri[(size_t)offT[c] + (gridCell[c].y++ & 255u)] = (uint32_t)(i - nS - nM);
+              { gridTri[(size_t)offT[c] + ((gridCell[c].y >> 4) & 255u)] = (uint32_t)(i - nS - nM); gridCell[c].y += 16u; }
             }
           });
+        {
+          // Empty space: per empty cell the distance to the nearest cell with an entry, largest over the axes
+          // (Chebyshev), at most 15 - the walk jumps skip - 1 cells at once there.  Two chamfer passes over the 26
+          // neighbours are exact for this metric.
+          std::vector<uint8_t> dist(nc);
+          for (size_t c = 0; c < nc; ++c) dist[c] = (cntS[c] || cntT[c]) ? 0 : 15;
+          auto at = [&](int x, int y, int z) -> uint8_t& { return dist[((size_t)z * n[1] + y) * n[0] + x]; };
+          for (int pass = 0; pass < 2; ++pass) {
+            const int z0 = pass ? n[2] - 1 : 0, z1 = pass ? -1 : n[2], dz = pass ? -1 : 1;
+            const int y0 = pass ? n[1] - 1 : 0, y1 = pass ? -1 : n[1];
+            const int x0 = pass ? n[0] - 1 : 0, x1 = pass ? -1 : n[0];
+            for (int z = z0; z != z1; z += dz)
+              for (int y = y0; y != y1; y += dz)
+                for (int x = x0; x != x1; x += dz) {
+                  uint8_t d = at(x, y, z);
+                  if (!d) continue;
+                  for (int oz = -1; oz <= 1; ++oz)
+                    for (int oy = -1; oy <= 1; ++oy)
+                      for (int ox = -1; ox <= 1; ++ox) {
+                        const int xx = x + ox, yy = y + oy, zz = z + oz;
+                        if (xx < 0 || yy < 0 || zz < 0 || xx >= n[0] || yy >= n[1] || zz >= n[2]) continue;
+                        d = std::min<uint8_t>(d, (uint8_t)std::min(15, at(xx, yy, zz) + 1));
+                      }
+                  at(x, y, z) = d;
+                }
+          }
+          for (size_t c = 0; c < nc; ++c) gridCell[c].y |= dist[c];
+        }
         for (int k = 0; k < 3; ++k) { G.n[k] = n[k]; G.lo[k] = blo[k]; G.hi[k] = bhi[k]; G.cs[k] = cs[k]; }
         G.far = 256. * E;
       }
@@ -775,6 +803,19 @@ int cftrt_scene_commit(cftrt_scene* s) {
     D.tKT1 = (float)(32. * eps * emax * emax);
     D.tKT2 = (float)(32. * eps * emax * emax * (pmax + emax));
     D.tKT3 = (float)(32. * eps * emax * emax);
+  }
+  if (getenv("CFTRT_DEBUG")) {
+    size_t emptyc = 0, far = 0;
+    uint32_t cmaxS = 0, cmaxT = 0;
+    for (const uint2& c : gridCell) {
+      if (!(c.x & 255u) && !((c.y >> 4) & 255u)) emptyc++;
+      if ((c.y & 15u) >= 3u) far++;
+      cmaxS = std::max(cmaxS, c.x & 255u); cmaxT = std::max(cmaxT, (c.y >> 4) & 255u);
+    }
+    fprintf(stderr, "cftrt commit: lists sphF %d msph %d triF %d mtri %d prec %d | big prefix sph %d msph %d tri %d | grid %d x %d x %d, "
+                    "%zu cells (%zu empty, %zu with skip >= 3), %zu sphere entries, %zu triangle entries, max per cell %u / %u\n",
+            D.n_sphF, D.n_msph, D.n_triF, D.n_mtri, D.n_prec, nb_sph, nb_msph, nb_tri, D.gnx, D.gny, D.gnz, gridCell.size(), emptyc, far,
+            gridSph.size(), gridTri.size(), cmaxS, cmaxT);
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   s->committed = true;
@@ -988,7 +1029,7 @@ struct PassBufs {
   float4* rad;
   uint32_t* counts;
 };
-static const size_t kShardWords = 2 * CFTRT_MAX_LEVELS + 8 + 128 + 2;   // used words of shard 0's block
+static const size_t kShardWords = 2 * CFTRT_MAX_LEVELS + 8 + 128 + 2 + 4 * 64;   // (+ walk counters of the diagnostic build)   // used words of shard 0's block
 static_assert(kShardWords <= CFT_SHARD_STRIDE, "shard 0's counters, statistics and stamps must fit its block");
 static const size_t kCountWords = (size_t)CFT_SHARDS * CFT_SHARD_STRIDE;   // shard s of level l: word s * CFT_SHARD_STRIDE + l; the rest in shard 0's block:   // (+ 64 stamp sums of 64 bits of the diagnostic build)
 static const size_t kStampWord = 2 * CFTRT_MAX_LEVELS + 2 + 8;   // even: 8-byte aligned behind a 256-byte aligned base
@@ -1204,6 +1245,12 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
         fprintf(stderr, "stamps level %u (%u rays): total %.0f cycles per 256 rays |", l, hc[l], (double)tot / trips);
         for (int p = 0; p < 8; ++p) fprintf(stderr, " %s %.1f%%", names[p], 100.0 * (double)sp[p] / (double)tot);
         fprintf(stderr, "\n");
+        const unsigned long long* wk = (const unsigned long long*)(hc + kStampWord + 128 + 2) + 32 * l;
+        if (l < 4 && wk[0])
+          fprintf(stderr, "  walk: %llu rays, cells/ray %.1f, entries/ray %.1f, candidate-path entries/ray %.2f | cells hist <4 <8 <16 <32 <64 64+: %.3f %.3f %.3f %.3f %.3f %.3f | entries hist <4..128+: %.3f %.3f %.3f %.3f %.3f %.3f %.3f\n",
+                  wk[0], (double)wk[1] / wk[0], (double)wk[2] / wk[0], (double)wk[3] / wk[0], (double)wk[8] / wk[0], (double)wk[9] / wk[0],
+                  (double)wk[10] / wk[0], (double)wk[11] / wk[0], (double)wk[12] / wk[0], (double)wk[13] / wk[0], (double)wk[16] / wk[0],
+                  (double)wk[17] / wk[0], (double)wk[18] / wk[0], (double)wk[19] / wk[0], (double)wk[20] / wk[0], (double)wk[21] / wk[0], (double)wk[22] / wk[0]);
       }
     }
 #endif

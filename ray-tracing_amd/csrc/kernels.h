@@ -41,6 +41,7 @@
 // k_trace_level trip, summed per wave and added to 64-bit words behind the level counters (phase p of level l < 8 at
 // stats + 8 + 2 (8 l + p)); CFTRT_STAMPS=1 makes the host print them.  Stamp values reach no output.
 #ifdef CFT_STAMPS
+static __device__ unsigned long long* g_walk_stats = nullptr;   // (diagnostic build: 32 counters of the grid walk, set per launch)
 #define CFT_STAMP_DECL uint64_t st_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t st_last_ = __builtin_amdgcn_s_memtime()
 #define CFT_STAMP(p) do { const uint64_t now_ = __builtin_amdgcn_s_memtime(); st_acc_[p] += now_ - st_last_; st_last_ = now_; } while (0)
 #define CFT_STAMP_FLUSH(stats, level)                                                                   \
@@ -660,16 +661,42 @@ __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>&
 #pragma unroll
   for (int k = 0; k < NS; ++k) hi[k] = inf;
   float tstop = inf;   // lower bound on the distance of every primitive the walk did not meet
-  // Cell record: one dword per kind, (first entry << 8) | count.  The walk runs one cell AHEAD of the tests: the step
+  // Cell record: x = (first sphere entry << 8) | count, y = (first triangle entry << 12) | (count << 4) | skip.
+  // The walk runs one cell AHEAD of the tests: the step
   // to the next cell does not depend on what the current cell holds, so the next record is requested before the
   // current cell's entries are tested and its latency hides under them (a wave has one ray per lane in flight and a
   // SIMD four such waves: the dependent record -> entries loads were what the walk waited for).
   const uint2* cells = S.gridCell;
   uint2 cell = cells[__umul24(__umul24((uint32_t)cz, (uint32_t)S.gny) + (uint32_t)cy, (uint32_t)S.gnx) + (uint32_t)cx];   // < 2^21
+  // |d_axis| / cell size = 1 / (distance between two planes of the axis): for the jumps over empty space below
+  const float rsx = fabsf(dx) * S.gicx, rsy = fabsf(dy) * S.gicy, rsz = fabsf(dz) * S.gicz;
+#ifdef CFT_STAMPS
+  uint32_t wk_cells = 0, wk_tests = 0, wk_pass = 0;
+#endif
   while (true) {
-    const float tnr = fminf(tmx, fminf(tmy, tmz));   // exit of this cell, from p
-    // step into the neighbour across the nearest plane (straight-line: three-way branches diverge)
-    {
+#ifdef CFT_STAMPS
+    wk_cells += 1; wk_tests += (cell.x & 255u) + ((cell.y >> 4) & 255u);
+#endif
+    float tnr;   // distance (from p) up to which the walk is done once this cell's entries are tested
+    const uint32_t skip = cell.y & 15u;   // empty cell: distance (in cells, on every axis) to the nearest cell with an entry
+    if (skip >= 3u) {
+      // EMPTY SPACE: every cell within skip - 1 of this one on every axis is empty too.  Go on to where the first axis
+      // has crossed skip - 1 planes; the other axes have then crossed at most as many, so nothing was passed over.
+      // (A crossing count that rounding gets one short only means that axis steps again at once.)
+      const float kf = (float)(skip - 2u);
+      const float ax_ = fabsf(sdx), ay_ = fabsf(sdy), az_ = fabsf(sdz);
+      const float ux = fmaf(kf, ax_, tmx), uy = fmaf(kf, ay_, tmy), uz = fmaf(kf, az_, tmz);
+      tnr = fminf(ux, fminf(uy, uz));
+      const int lim = (int)skip - 1;
+      int nx = tnr >= tmx ? min(lim, 1 + (int)((tnr - tmx) * rsx)) : 0;
+      int ny = tnr >= tmy ? min(lim, 1 + (int)((tnr - tmy) * rsy)) : 0;
+      int nz = tnr >= tmz ? min(lim, 1 + (int)((tnr - tmz) * rsz)) : 0;
+      if (ux <= uy && ux <= uz) nx = lim; else if (uy <= uz) ny = lim; else nz = lim;
+      cx += stx * nx; cy += sty * ny; cz += stz * nz;
+      tmx = fmaf((float)nx, ax_, tmx); tmy = fmaf((float)ny, ay_, tmy); tmz = fmaf((float)nz, az_, tmz);
+    } else {
+      tnr = fminf(tmx, fminf(tmy, tmz));   // exit of this cell, from p
+      // step into the neighbour across the nearest plane (straight-line: three-way branches diverge)
       const bool ax = tmx <= tmy && tmx <= tmz, ay = !ax && tmy <= tmz, az = !ax && !ay;
       cx += ax ? stx : 0; cy += ay ? sty : 0; cz += az ? stz : 0;
       tmx += ax ? fabsf(sdx) : 0.0f; tmy += ay ? fabsf(sdy) : 0.0f; tmz += az ? fabsf(sdz) : 0.0f;
@@ -678,18 +705,35 @@ __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>&
     uint2 next = make_uint2(0u, 0u);
     if (inside && tnr <= tendr)
       next = cells[__umul24(__umul24((uint32_t)cz, (uint32_t)S.gny) + (uint32_t)cy, (uint32_t)S.gnx) + (uint32_t)cx];
-    for (uint32_t e = cell.x >> 8, ee = (cell.x >> 8) + (cell.x & 255u); e < ee; ++e) {
-      const float4 a = S.gridSph[e];   // one 16 B load per test: divergent loads are what the walk is bound by
-      // the per-ray cull of scan_sphere, unpacked (same operations in the same order): q = 2 oc.d, pass iff the
-      // LINE meets the sphere.  Two cheap rejects keep lanes out of the (divergent) candidate path:
-      //  * behind: origin certainly outside (c + k4 = 4 (|oc|^2 - r^2) - 4 E + err > 0, the margin E inside thr4
-      //    exceeds err) and certainly moving away (q > eQ): both roots negative;
-      //  * seen: the primitive is already an indexed candidate (it sits in every cell it overlaps).
-      float q = fmaf(a.z, dz, PK(P, od2, r)), c = fmaf(a.z, PK(P, o4z, r), PK(P, thr4, r));
-      q = fmaf(a.y, dy, q); c = fmaf(a.y, PK(P, o4y, r), c);
-      q = fmaf(a.x, dx, q); c = fmaf(a.x, PK(P, o4x, r), c);
-      const bool behind = q > eQ && c + a.w > 0.0f;
-      if (fmaf(q, q, -c) >= a.w && !behind) {
+    // The cell's sphere entries, FOUR at a time: the four 16 B loads are in flight together (one after the other they
+    // were a chain of dependent round trips: a cell of a 20 k-primitive scene holds up to 19 entries), the cull of each
+    // is 8 FMAs, and only entries that pass go on to the (rare, divergent) candidate path.
+    for (uint32_t e0 = cell.x >> 8, ee = (cell.x >> 8) + (cell.x & 255u); e0 < ee; e0 += 4u) {
+      float4 a4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a4[j] = S.gridSph[min(e0 + (uint32_t)j, ee - 1u)];
+      uint32_t pass = 0u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // the per-ray cull of scan_sphere, unpacked (same operations in the same order): q = 2 oc.d, pass iff the
+        // LINE meets the sphere.  Two cheap rejects keep lanes out of the (divergent) candidate path:
+        //  * behind: origin certainly outside (c + k4 = 4 (|oc|^2 - r^2) - 4 E + err > 0, the margin E inside thr4
+        //    exceeds err) and certainly moving away (q > eQ): both roots negative;
+        //  * seen (below): the primitive is already an indexed candidate (it sits in every cell it overlaps).
+        const float4 a = a4[j];
+        float q = fmaf(a.z, dz, PK(P, od2, r)), c = fmaf(a.z, PK(P, o4z, r), PK(P, thr4, r));
+        q = fmaf(a.y, dy, q); c = fmaf(a.y, PK(P, o4y, r), c);
+        q = fmaf(a.x, dx, q); c = fmaf(a.x, PK(P, o4x, r), c);
+        const bool behind = q > eQ && c + a.w > 0.0f;
+        if (e0 + (uint32_t)j < ee && fmaf(q, q, -c) >= a.w && !behind) pass |= 1u << j;
+      }
+      while (pass) {
+#ifdef CFT_STAMPS
+        wk_pass += 1;
+#endif
+        const uint32_t e = e0 + (uint32_t)__builtin_ctz(pass);
+        pass &= pass - 1u;
+        const float4 a = S.gridSph[e];    // (again: the batch sits in registers under a constant index only)
         const float2 b = S.gridSphX[e];   // (16 r^2, list index)
         const int idx = __float_as_int(b.y);
         bool seen = true;
@@ -705,7 +749,7 @@ __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>&
       }
     }
     if (LISTS & 2) {
-      for (uint32_t e = cell.y >> 8, ee = (cell.y >> 8) + (cell.y & 255u); e < ee; ++e) {
+      for (uint32_t e = cell.y >> 12, ee = (cell.y >> 12) + ((cell.y >> 4) & 255u); e < ee; ++e) {
         const int s = (int)S.gridTri[e];
         const float4 p0 = S.triF[3 * s], e1 = S.triF[3 * s + 1], e2 = S.triF[3 * s + 2];
         float thi = inf;
@@ -736,6 +780,17 @@ __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>&
   }
 #pragma unroll
   for (int k = 0; k < NS; ++k) P.c[k][r].lo3 = fminf(P.c[k][r].lo3, tstop);
+#ifdef CFT_STAMPS
+  if (g_walk_stats) {
+    atomicAdd(&g_walk_stats[0], 1ull); atomicAdd(&g_walk_stats[1], (unsigned long long)wk_cells);
+    atomicAdd(&g_walk_stats[2], (unsigned long long)wk_tests); atomicAdd(&g_walk_stats[3], (unsigned long long)wk_pass);
+    // histogram of cells walked: bins 0-3, 4-7, 8-15, 16-31, 32-63, 64+
+    const int bin = wk_cells < 4 ? 0 : wk_cells < 8 ? 1 : wk_cells < 16 ? 2 : wk_cells < 32 ? 3 : wk_cells < 64 ? 4 : 5;
+    atomicAdd(&g_walk_stats[8 + bin], 1ull);
+    const int tb = wk_tests < 4 ? 0 : wk_tests < 8 ? 1 : wk_tests < 16 ? 2 : wk_tests < 32 ? 3 : wk_tests < 64 ? 4 : wk_tests < 128 ? 5 : 6;
+    atomicAdd(&g_walk_stats[16 + tb], 1ull);
+  }
+#endif
 }
 
 // Moving triangles (4 float4 each: p0, e1, e2, (mv, object id)), once per scan with that scan's motion time.
@@ -1800,6 +1855,9 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(SceneDev S, QueueD
     else return base + r * 64u < n ? base + r * 64u : 0xFFFFFFFFu;
   };
   CFT_STAMP_DECL;
+#ifdef CFT_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x == 0) g_walk_stats = level < 4u ? (unsigned long long*)(stats + 8 + 128 + 2) + 32 * level : nullptr;
+#endif
   for (uint32_t it = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (CFT_BLOCK / 64u) + (threadIdx.x >> 6)));
        it < trips_to[CFT_SHARDS]; it += gridDim.x * (CFT_BLOCK / 64u)) {
     uint32_t seg = 0;

@@ -42,7 +42,8 @@ struct SceneDev {
   const int* mtri_gid;
   int n_mtri;
   // ---- uniform grid over the lists above (an extension; 0 cells = none).  Cell (x, y, z) -> gridCell[(z*gny + y)*gnx + x]
-  const uint2* gridCell;  // (sphere entries, triangle entries), each (first entry << 8) | count
+  const uint2* gridCell;  // x = (first sphere entry << 8) | count; y = (first triangle entry << 12) | (count << 4) | skip,
+                          // skip = for an empty cell, the distance in cells (largest over the axes, at most 15) to the nearest cell with an entry
   const float4* gridSph;  // per entry: the sphF / msphB entry
   const float2* gridSphX; // per entry: (16 r^2, list index bits), read when the cull passes
   const uint32_t* gridTri;   // index into triF
