@@ -931,6 +931,8 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
   }
   const uint32_t g = grid_for(ctx, ((uint64_t)P + R - 1) / R, 8);
   const GenArgs no_gen{};
+  // (experiments: unused dynamic LDS per block lowers the number of resident blocks per CU)
+  static const uint32_t dyn_lds = getenv("CFTRT_EXTRA_LDS") ? (uint32_t)atoi(getenv("CFTRT_EXTRA_LDS")) : 0u;
   // sharded output: trips of this launch <= ceil(P / 64 R) + one partial trip per input segment; segment `it mod 8`
   // receives the survivors of every 8th trip
   uint32_t out_k = 1, out_D = 0;
@@ -942,10 +944,10 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
   }
 #define CFT_LAUNCH(RR, NN, LL)                                                                                              \
   do {                                                                                                                      \
-    if (gen) hipLaunchKernelGGL((k_trace_level<RR, NN, LL, true>), dim3(g), dim3(CFT_BLOCK), 0, st, S, q, counts, level,     \
+    if (gen) hipLaunchKernelGGL((k_trace_level<RR, NN, LL, true>), dim3(g), dim3(CFT_BLOCK), dyn_lds, st, S, q, counts, level,     \
                                 max_depth, pid_base, k0, k1, role0, role1, qout, rad, pq, phong_counts, xstats, *gen, in_D,  \
                                 out_k, out_D);                                                                              \
-    else hipLaunchKernelGGL((k_trace_level<RR, NN, LL, false>), dim3(g), dim3(CFT_BLOCK), 0, st, S, q, counts, level,        \
+    else hipLaunchKernelGGL((k_trace_level<RR, NN, LL, false>), dim3(g), dim3(CFT_BLOCK), dyn_lds, st, S, q, counts, level,        \
                             max_depth, pid_base, k0, k1, role0, role1, qout, rad, pq, phong_counts, xstats, no_gen, in_D,   \
                             out_k, out_D);                                                                                  \
   } while (0)
@@ -1120,7 +1122,8 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
   SceneDev S = s->dev;
   S.wave_cull = ctx->wave_cull;
   S.grid_mode = S.gnx ? ctx->grid : 0;
-  if (S.grid_mode == 1 && S.n_sphF + S.n_msph + S.n_triF > 4096) S.grid_mode = 2;   // long lists: every wave walks
+  static const int promote_above = getenv("CFTRT_GRID_PROMOTE") ? atoi(getenv("CFTRT_GRID_PROMOTE")) : 4096;
+  if (S.grid_mode == 1 && S.n_sphF + S.n_msph + S.n_triF > promote_above) S.grid_mode = 2;   // long lists: every wave walks
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
   const bool phong = S.n_phong_mats > 0;
   const bool two_scans = S.any_motion && S.n_lights > 0;   // `looked` and trace each draw their own motion times
@@ -1251,6 +1254,10 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
                   wk[0], (double)wk[1] / wk[0], (double)wk[2] / wk[0], (double)wk[3] / wk[0], (double)wk[8] / wk[0], (double)wk[9] / wk[0],
                   (double)wk[10] / wk[0], (double)wk[11] / wk[0], (double)wk[12] / wk[0], (double)wk[13] / wk[0], (double)wk[16] / wk[0],
                   (double)wk[17] / wk[0], (double)wk[18] / wk[0], (double)wk[19] / wk[0], (double)wk[20] / wk[0], (double)wk[21] / wk[0], (double)wk[22] / wk[0]);
+        if (l < 4 && wk[24])   // the one-loop walk: per trip (one call of a wave), the passes of each phase and the lanes in them
+          fprintf(stderr, "  walk loop: %.0f calls | per call: rounds %.1f, set-up passes %.1f (%.1f lanes), search steps %.1f (%.1f lanes), candidate passes %.1f (%.1f lanes)\n",
+                  trips, (double)wk[24] / trips, (double)wk[25] / trips, (double)wk[26] / (double)(wk[25] ? wk[25] : 1), (double)wk[27] / trips,
+                  (double)wk[28] / (double)(wk[27] ? wk[27] : 1), (double)wk[29] / trips, (double)wk[30] / (double)(wk[29] ? wk[29] : 1));
       }
     }
 #endif
