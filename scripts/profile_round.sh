@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the rocprofv3 evidence under profiles/ for the default bench (run on the GPU box from the repo root):
-#   bash scripts/profile_round.sh v4      -> gpurun_out/prof_v4/*  (copy what is to be judged into profiles/)
+#   bash scripts/profile_round.sh r02     -> gpurun_out/prof_r02/*  (copy what is to be judged into profiles/ as r02_*)
 # Kernel trace and counters are separate runs; each --pmc pass is its own run within the per-block counter limits.
 set -e
 tag=$1
@@ -13,9 +13,9 @@ python3 scripts/level_times.py $out/stats > $out/level_times.txt
 CFTRT_GRID=0 CFTRT_WAVE_CULL=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_plain -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-plain-scan > $out/bench_plain_scan_under_rocprof.json
 cp $out/stats_plain/p_kernel_stats.csv $out/kernel_stats_plain_scan.csv
 timeout -k 10 400 python3 bench.py > $out/bench.json
-bash scripts/pmc_pass.sh ${tag}_sq 0 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE
-bash scripts/pmc_pass.sh ${tag}_lds 0 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_LEVEL_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
-bash scripts/pmc_pass.sh ${tag}_tcp 0 TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE
+PMC_WARMUP=1 bash scripts/pmc_pass.sh ${tag}_sq 0 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE
+PMC_WARMUP=1 bash scripts/pmc_pass.sh ${tag}_lds 0 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_LEVEL_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
+PMC_WARMUP=1 bash scripts/pmc_pass.sh ${tag}_tcp 0 TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE
 PMC_WARMUP=1 bash scripts/pmc_pass.sh ${tag}_fetch 0 FETCH_SIZE
 PMC_WARMUP=1 bash scripts/pmc_pass.sh ${tag}_write 0 WRITE_SIZE
 rays=$(python3 -c "import json;print(json.load(open('$out/bench_under_rocprof.json'))['config']['rays_per_step_per_gpu'])")
@@ -23,4 +23,14 @@ python3 scripts/hbm_traffic.py gpurun_out/pmc_${tag}_fetch gpurun_out/pmc_${tag}
 cp gpurun_out/pmc_${tag}_sq.json $out/pmc_sq.json
 cp gpurun_out/pmc_${tag}_lds.json $out/pmc_lds_occupancy.json
 cp gpurun_out/pmc_${tag}_tcp.json $out/pmc_ta_tcp.json
+# C2 cornell (the reference's own second scene): kernel times and the SQ counters that name its bound
+bash scripts/trace_config.sh ${tag}_c2 C2 > $out/c2_level_times.txt
+bash scripts/pmc_config.sh ${tag}_c2_sq C2 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE
+cp gpurun_out/pmc_${tag}_c2_sq.json $out/pmc_sq_c2_cornell.json
+cp gpurun_out/trace_${tag}_c2/p_kernel_stats.csv $out/kernel_stats_c2_cornell.csv
+# C5 S20k (grid walk at every level): per-level times and SQ / TA counters
+bash scripts/trace_config.sh ${tag}_c5 C5 > $out/c5_level_times.txt
+bash scripts/pmc_config.sh ${tag}_c5_sq C5 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
+cp gpurun_out/pmc_${tag}_c5_sq.json $out/pmc_sq_c5_s20k.json
+python3 scripts/bench_configs.py C1 C2 C2p C3 C5 C4 > $out/configs.jsonl
 ls -la $out
