@@ -62,7 +62,7 @@ def cpu_baseline():
 
 def committed_profile(pattern):
     """Newest committed profile summary matching profiles/<pattern> (round-tagged names sort by round)."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    files = sorted(f for pat in pattern.split("|") for f in glob.glob(os.path.join(ROOT, "profiles", pat)))
     if not files:
         return None, None
     try:
@@ -90,7 +90,7 @@ def as_run_utilisation():
     (scripts/pmc_summary.py over `rocprofv3 --pmc SQ_*`): per kernel instance, VALU busy = SQ_ACTIVE_INST_VALU x 4 /
     (SIMDs x cycles), lanes active per VALU instruction = SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU), and their
     product, the share of the chip's VALU lane-cycles that did work."""
-    d, name = committed_profile("r0*_pmc_sq*.json")
+    d, name = committed_profile("r0*_pmc_sq.json|r0*_pmc_sq_v*.json")   # (the S500 frame, not the per-config passes)
     if not d:
         return None
     out = {"source": "profiles/" + name, "kernels": []}
