@@ -189,17 +189,17 @@ int cftrt_ctx_create(int device, cftrt_ctx** out) {
   // this device's address of the static workspace (each GPU has its own copy of the array); `device` is current here
   if ((e = hipGetSymbolAddress((void**)&ctx->static_scratch, HIP_SYMBOL(scratch))) != hipSuccess || !ctx->static_scratch) {
     g_create_error = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e);
-    hipStreamDestroy(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return CFTRT_ERR_HIP;
   }
-  hipEventCreate(&ctx->ev_t0);
-  hipEventCreate(&ctx->ev_t1);
+  (void)hipEventCreate(&ctx->ev_t0);
+  (void)hipEventCreate(&ctx->ev_t1);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
   if ((e = hipHostMalloc((void**)&ctx->host_counts, (size_t)CFT_SHARDS * CFT_SHARD_STRIDE * sizeof(uint32_t))) != hipSuccess) {
     g_create_error = std::string("hipHostMalloc: ") + hipGetErrorString(e);
-    hipStreamDestroy(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return CFTRT_ERR_HIP;
   }
@@ -210,18 +210,18 @@ int cftrt_ctx_create(int device, cftrt_ctx** out) {
 void cftrt_ctx_destroy(cftrt_ctx* ctx) {
   if (!ctx) return;
   DeviceGuard guard(ctx->device);
-  hipStreamSynchronize(ctx->stream);
+  (void)hipStreamSynchronize(ctx->stream);
   if (ctx->comm) (void)cftrt_comm_destroy(ctx);
   DevBuf* bufs[] = {&ctx->qa[0], &ctx->qa[1], &ctx->qb[0], &ctx->qb[1], &ctx->qc[0], &ctx->qc[1], &ctx->h0[0],
                     &ctx->h0[1], &ctx->h1[0], &ctx->h1[1], &ctx->ht[0], &ctx->ht[1], &ctx->rad, &ctx->pqa, &ctx->pqb, &ctx->pqc,
                     &ctx->pqd, &ctx->counts, &ctx->accum_tmp, &ctx->misc};
   for (DevBuf* b : bufs)
-    if (b->p) hipFree(b->p);
-  for (hipEvent_t ev : ctx->events) hipEventDestroy(ev);
-  if (ctx->ev_t0) hipEventDestroy(ctx->ev_t0);
-  if (ctx->ev_t1) hipEventDestroy(ctx->ev_t1);
-  if (ctx->host_counts) hipHostFree(ctx->host_counts);
-  hipStreamDestroy(ctx->stream);
+    if (b->p) (void)hipFree(b->p);
+  for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
+  if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);
+  if (ctx->ev_t1) (void)hipEventDestroy(ctx->ev_t1);
+  if (ctx->host_counts) (void)hipHostFree(ctx->host_counts);
+  (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
 
@@ -288,8 +288,8 @@ int cftrt_scene_create(cftrt_ctx* ctx, cftrt_scene** out) {
 void cftrt_scene_destroy(cftrt_scene* s) {
   if (!s) return;
   DeviceGuard guard(s->ctx->device);
-  hipStreamSynchronize(s->ctx->stream);
-  for (void* p : s->dev_allocs) hipFree(p);
+  (void)hipStreamSynchronize(s->ctx->stream);
+  for (void* p : s->dev_allocs) (void)hipFree(p);
   delete s;
 }
 
@@ -1004,7 +1004,6 @@ struct EvTimer {
     open = true;
     return 0;
   }
-  void end() {}
   void flush() {
     if (open) (void)hipEventRecord(ctx->events[spans.back().first + 1], ctx->stream);
     open = false;
@@ -1148,7 +1147,6 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
   if (ctx->split) {   // the fused pipeline generates inside its level-0 launch
     if (tm.begin(CLS_GEN)) return fail(ctx, CFTRT_ERR_HIP, "hipEventCreate failed");
     hipLaunchKernelGGL(k_generate, dim3(grid_for(ctx, P, 16)), dim3(CFT_BLOCK), 0, st_, C, pid_base, P, k0, k1, jitter, tiled, q[0]);
-    tm.end();
   }
 
   uint32_t ub = P;   // upper bound on the live rays of the current level (a ray spawns at most one ray)
@@ -1171,21 +1169,17 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
       launch_trace_level(ctx, S, q[in], counts, level, max_depth, pid_base, k0, k1, two_scans, two_scans ? looked_role : nl, nl,
                          q[outq], rad, pq, phong_counts, xstats, ub, level == 0 ? &gen : nullptr, in_D, &out_D);
       in_D = out_D;
-      tm.end();
     } else {
       tm.begin(CLS_ISECT);
       launch_intersect(ctx, S, q[in], counts, level, pid_base, k0, k1, two_scans, two_scans ? looked_role : nl, nl, hA, hB, xstats, ub);
-      tm.end();
       tm.begin(CLS_SHADE);
       hipLaunchKernelGGL(k_shade, dim3(grid), dim3(CFT_BLOCK), 0, st_, S, q[in], hA, hB, counts, level, max_depth,
                          pid_base, k0, k1, q[outq], rad, pq, phong_counts);
-      tm.end();
     }
     if (phong) {
       tm.begin(CLS_SHADOW);
       hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(CFT_BLOCK), 0, st_, S, pq, phong_counts, level, pid_base, k0, k1, rad,
                          xstats);
-      tm.end();
     }
     levels_run = level + 1;
     // every 4 levels (every 16 once the launches are latency-bound: a peek idles the GPU for ~35 us) look at the
@@ -1209,7 +1203,6 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
         const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)ub + CFT_BLOCK - 1) / CFT_BLOCK, (uint64_t)ctx->n_cu * 8));
         hipLaunchKernelGGL(k_trace_finish, dim3(blocks), dim3(CFT_BLOCK), 0, st_, S, q[outq], counts, level + 1, max_depth,
                            pid_base, k0, k1, two_scans ? looked_role : nl, nl, two_scans ? 1 : 0, rad, xstats + 2, xstats, in_D);
-        tm.end();
         levels_run = max_depth;
         break;
       }
@@ -1218,7 +1211,6 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
   if (accum_dev) {
     tm.begin(CLS_RESOLVE);
     hipLaunchKernelGGL(k_resolve, dim3(grid_for(ctx, npix, 16)), dim3(CFT_BLOCK), 0, st_, rad, npix, nsamples, accum_dev);
-    tm.end();
   }
   tm.flush();
   HIP_TRY(ctx, hipMemcpyAsync(ctx->host_counts, counts, ncount * 4, hipMemcpyDeviceToHost, st_));
@@ -1307,7 +1299,7 @@ static int render_impl(cftrt_scene* s, const cftrt_camera* cam, uint32_t width, 
   HIP_TRY(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   float msT = 0.f;
-  hipEventElapsedTime(&msT, ctx->ev_t0, ctx->ev_t1);
+  (void)hipEventElapsedTime(&msT, ctx->ev_t0, ctx->ev_t1);
   st.ms_total = msT;
   st.ms_generate = ms[CLS_GEN];
   st.ms_intersect = ms[CLS_ISECT];

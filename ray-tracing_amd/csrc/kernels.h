@@ -250,7 +250,6 @@ __device__ __forceinline__ void cand_init(Cand& c) {
   c.i1 = c.i2 = -1;
 }
 __device__ __forceinline__ void cand_insert(Cand& c, float tlo, int idx) {
-#if 1
   // straight-line: masks + bitfield selects (nested ?: compiles to nested exec-mask branches)
   const int m1 = (tlo < c.lo1) ? -1 : 0, m2 = (tlo < c.lo2) ? -1 : 0;
   c.lo3 = __builtin_amdgcn_fmed3f(c.lo2, c.lo3, tlo);
@@ -259,14 +258,6 @@ __device__ __forceinline__ void cand_insert(Cand& c, float tlo, int idx) {
   c.lo2 = __builtin_amdgcn_fmed3f(c.lo1, c.lo2, tlo);
   c.i1 = (m1 & idx) | (~m1 & c.i1);
   c.lo1 = fminf(c.lo1, tlo);
-#else
-  const bool c1 = tlo < c.lo1, c2 = tlo < c.lo2;
-  c.lo3 = __builtin_amdgcn_fmed3f(c.lo2, c.lo3, tlo);
-  c.i2 = c1 ? c.i1 : (c2 ? idx : c.i2);
-  c.lo2 = __builtin_amdgcn_fmed3f(c.lo1, c.lo2, tlo);
-  c.i1 = c1 ? idx : c.i1;
-  c.lo1 = fminf(c.lo1, tlo);
-#endif
 }
 
 #define CFT_U4EPS 2.3841858e-7f   // 4 * 2^-24: slack for a 1-ulp sqrt/rcp and the final adds
