@@ -639,34 +639,6 @@ int cftrt_scene_commit(cftrt_scene* s) {
               { gridTri[(size_t)offT[c] + ((gridCell[c].y >> 4) & 255u)] = (uint32_t)(i - nS - nM); gridCell[c].y += 16u; }
             }
           });
-        {
-          // Empty space: per empty cell the distance to the nearest cell with an entry, largest over the axes
-          // (Chebyshev), at most 15 - the walk jumps skip - 1 cells at once there.  Two chamfer passes over the 26
-          // neighbours are exact for this metric.
-          std::vector<uint8_t> dist(nc);
-          for (size_t c = 0; c < nc; ++c) dist[c] = (cntS[c] || cntT[c]) ? 0 : 15;
-          auto at = [&](int x, int y, int z) -> uint8_t& { return dist[((size_t)z * n[1] + y) * n[0] + x]; };
-          for (int pass = 0; pass < 2; ++pass) {
-            const int z0 = pass ? n[2] - 1 : 0, z1 = pass ? -1 : n[2], dz = pass ? -1 : 1;
-            const int y0 = pass ? n[1] - 1 : 0, y1 = pass ? -1 : n[1];
-            const int x0 = pass ? n[0] - 1 : 0, x1 = pass ? -1 : n[0];
-            for (int z = z0; z != z1; z += dz)
-              for (int y = y0; y != y1; y += dz)
-                for (int x = x0; x != x1; x += dz) {
-                  uint8_t d = at(x, y, z);
-                  if (!d) continue;
-                  for (int oz = -1; oz <= 1; ++oz)
-                    for (int oy = -1; oy <= 1; ++oy)
-                      for (int ox = -1; ox <= 1; ++ox) {
-                        const int xx = x + ox, yy = y + oy, zz = z + oz;
-                        if (xx < 0 || yy < 0 || zz < 0 || xx >= n[0] || yy >= n[1] || zz >= n[2]) continue;
-                        d = std::min<uint8_t>(d, (uint8_t)std::min(15, at(xx, yy, zz) + 1));
-                      }
-                  at(x, y, z) = d;
-                }
-          }
-          for (size_t c = 0; c < nc; ++c) gridCell[c].y |= dist[c];
-        }
         for (int k = 0; k < 3; ++k) { G.n[k] = n[k]; G.lo[k] = blo[k]; G.hi[k] = bhi[k]; G.cs[k] = cs[k]; }
         G.far = 256. * E;
       }
@@ -805,16 +777,15 @@ int cftrt_scene_commit(cftrt_scene* s) {
     D.tKT3 = (float)(32. * eps * emax * emax);
   }
   if (getenv("CFTRT_DEBUG")) {
-    size_t emptyc = 0, far = 0;
+    size_t emptyc = 0;
     uint32_t cmaxS = 0, cmaxT = 0;
     for (const uint2& c : gridCell) {
       if (!(c.x & 255u) && !((c.y >> 4) & 255u)) emptyc++;
-      if ((c.y & 15u) >= 3u) far++;
       cmaxS = std::max(cmaxS, c.x & 255u); cmaxT = std::max(cmaxT, (c.y >> 4) & 255u);
     }
     fprintf(stderr, "cftrt commit: lists sphF %d msph %d triF %d mtri %d prec %d | big prefix sph %d msph %d tri %d | grid %d x %d x %d, "
-                    "%zu cells (%zu empty, %zu with skip >= 3), %zu sphere entries, %zu triangle entries, max per cell %u / %u\n",
-            D.n_sphF, D.n_msph, D.n_triF, D.n_mtri, D.n_prec, nb_sph, nb_msph, nb_tri, D.gnx, D.gny, D.gnz, gridCell.size(), emptyc, far,
+                    "%zu cells (%zu empty), %zu sphere entries, %zu triangle entries, max per cell %u / %u\n",
+            D.n_sphF, D.n_msph, D.n_triF, D.n_mtri, D.n_prec, nb_sph, nb_msph, nb_tri, D.gnx, D.gny, D.gnz, gridCell.size(), emptyc,
             gridSph.size(), gridTri.size(), cmaxS, cmaxT);
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -616,6 +616,9 @@ __device__ __forceinline__ void scan_msphere(const SceneDev& S, RayPack<R, NS>& 
 //    (ray_epilogue) - the stop needs no trust in the certificate.
 // Rays that start farther than 256 E from the scene centre are not walked: in the level kernels they go to the exact
 // f64 rescan (lo3 = 0), in the one-ray form closest_hit the wave scans the lists.
+#ifndef CFT_WALK_BATCH
+#define CFT_WALK_BATCH 2   // sphere entries of a cell tested per round of loads (measured: 2 beats 1 and 4 on S500 and S20k)
+#endif
 template <int R, int NS, int LISTS>
 __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>& P, int r) {
   const float inf = __builtin_inff();
@@ -652,15 +655,13 @@ __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>&
 #pragma unroll
   for (int k = 0; k < NS; ++k) hi[k] = inf;
   float tstop = inf;   // lower bound on the distance of every primitive the walk did not meet
-  // Cell record: x = (first sphere entry << 8) | count, y = (first triangle entry << 12) | (count << 4) | skip.
+  // Cell record: x = (first sphere entry << 8) | count, y = (first triangle entry << 12) | (count << 4).
   // The walk runs one cell AHEAD of the tests: the step
   // to the next cell does not depend on what the current cell holds, so the next record is requested before the
   // current cell's entries are tested and its latency hides under them (a wave has one ray per lane in flight and a
   // SIMD four such waves: the dependent record -> entries loads were what the walk waited for).
   const uint2* cells = S.gridCell;
   uint2 cell = cells[__umul24(__umul24((uint32_t)cz, (uint32_t)S.gny) + (uint32_t)cy, (uint32_t)S.gnx) + (uint32_t)cx];   // < 2^21
-  // |d_axis| / cell size = 1 / (distance between two planes of the axis): for the jumps over empty space below
-  const float rsx = fabsf(dx) * S.gicx, rsy = fabsf(dy) * S.gicy, rsz = fabsf(dz) * S.gicz;
 #ifdef CFT_STAMPS
   uint32_t wk_cells = 0, wk_tests = 0, wk_pass = 0;
 #endif
@@ -668,26 +669,8 @@ __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>&
 #ifdef CFT_STAMPS
     wk_cells += 1; wk_tests += (cell.x & 255u) + ((cell.y >> 4) & 255u);
 #endif
-    float tnr;   // distance (from p) up to which the walk is done once this cell's entries are tested
-    const uint32_t skip = cell.y & 15u;   // empty cell: distance (in cells, on every axis) to the nearest cell with an entry
-    if (skip >= 3u) {
-      // EMPTY SPACE: every cell within skip - 1 of this one on every axis is empty too.  Go on to where the first axis
-      // has crossed skip - 1 planes; the other axes have then crossed at most as many, so nothing was passed over.
-      // (A crossing count that rounding gets one short only means that axis steps again at once.)
-      const float kf = (float)(skip - 2u);
-      const float ax_ = fabsf(sdx), ay_ = fabsf(sdy), az_ = fabsf(sdz);
-      const float ux = fmaf(kf, ax_, tmx), uy = fmaf(kf, ay_, tmy), uz = fmaf(kf, az_, tmz);
-      tnr = fminf(ux, fminf(uy, uz));
-      const int lim = (int)skip - 1;
-      int nx = tnr >= tmx ? min(lim, 1 + (int)((tnr - tmx) * rsx)) : 0;
-      int ny = tnr >= tmy ? min(lim, 1 + (int)((tnr - tmy) * rsy)) : 0;
-      int nz = tnr >= tmz ? min(lim, 1 + (int)((tnr - tmz) * rsz)) : 0;
-      if (ux <= uy && ux <= uz) nx = lim; else if (uy <= uz) ny = lim; else nz = lim;
-      cx += stx * nx; cy += sty * ny; cz += stz * nz;
-      tmx = fmaf((float)nx, ax_, tmx); tmy = fmaf((float)ny, ay_, tmy); tmz = fmaf((float)nz, az_, tmz);
-    } else {
-      tnr = fminf(tmx, fminf(tmy, tmz));   // exit of this cell, from p
-      // step into the neighbour across the nearest plane (straight-line: three-way branches diverge)
+    const float tnr = fminf(tmx, fminf(tmy, tmz));   // exit of this cell, from p
+    {   // step into the neighbour across the nearest plane (straight-line: three-way branches diverge)
       const bool ax = tmx <= tmy && tmx <= tmz, ay = !ax && tmy <= tmz, az = !ax && !ay;
       cx += ax ? stx : 0; cy += ay ? sty : 0; cz += az ? stz : 0;
       tmx += ax ? fabsf(sdx) : 0.0f; tmy += ay ? fabsf(sdy) : 0.0f; tmz += az ? fabsf(sdz) : 0.0f;
@@ -696,16 +679,17 @@ __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>&
     uint2 next = make_uint2(0u, 0u);
     if (inside && tnr <= tendr)
       next = cells[__umul24(__umul24((uint32_t)cz, (uint32_t)S.gny) + (uint32_t)cy, (uint32_t)S.gnx) + (uint32_t)cx];
-    // The cell's sphere entries, FOUR at a time: the four 16 B loads are in flight together (one after the other they
-    // were a chain of dependent round trips: a cell of a 20 k-primitive scene holds up to 19 entries), the cull of each
-    // is 8 FMAs, and only entries that pass go on to the (rare, divergent) candidate path.
-    for (uint32_t e0 = cell.x >> 8, ee = (cell.x >> 8) + (cell.x & 255u); e0 < ee; e0 += 4u) {
-      float4 a4[4];
+    // The cell's sphere entries, CFT_WALK_BATCH at a time: the 16 B loads of a batch are in flight together (one after
+    // the other they are a chain of dependent round trips: a cell of a 20 k-primitive scene holds up to 19 entries),
+    // the cull of each is 8 FMAs, and only entries that pass go on to the (rare, divergent) candidate path.  A cell
+    // visited holds 1.3 (S500) to 2.2 (S20k) entries on average: batches of 4 mostly test clamped repeats.
+    for (uint32_t e0 = cell.x >> 8, ee = (cell.x >> 8) + (cell.x & 255u); e0 < ee; e0 += (uint32_t)CFT_WALK_BATCH) {
+      float4 a4[CFT_WALK_BATCH];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) a4[j] = S.gridSph[min(e0 + (uint32_t)j, ee - 1u)];
+      for (int j = 0; j < CFT_WALK_BATCH; ++j) a4[j] = S.gridSph[min(e0 + (uint32_t)j, ee - 1u)];
       uint32_t pass = 0u;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < CFT_WALK_BATCH; ++j) {
         // the per-ray cull of scan_sphere, unpacked (same operations in the same order): q = 2 oc.d, pass iff the
         // LINE meets the sphere.  Two cheap rejects keep lanes out of the (divergent) candidate path:
         //  * behind: origin certainly outside (c + k4 = 4 (|oc|^2 - r^2) - 4 E + err > 0, the margin E inside thr4
