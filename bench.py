@@ -155,6 +155,8 @@ def main():
     if os.environ.get("CFTRT_FINISH"):
         f = os.environ["CFTRT_FINISH"].split(",")              # "on[,below]": deep levels path by path (profiling)
         dev.set_finish(int(f[0]), int(f[1]) if len(f) > 1 else 0)
+    if os.environ.get("CFTRT_TILE_LISTS"):
+        dev.set_tile_lists(int(os.environ["CFTRT_TILE_LISTS"]))
     if os.environ.get("CFTRT_SHARDS"):
         dev.set_shards(int(os.environ["CFTRT_SHARDS"]))
     scene.commit(dev)

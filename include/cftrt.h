@@ -148,6 +148,14 @@ int cftrt_ctx_set_grid(cftrt_ctx* ctx, int mode, double cells_per_prim);
  * chip-wide, one per 256 rays).  The image does not depend on the order of the queue: same image bit for bit; the
  * switch exists for that comparison and for profiling. */
 int cftrt_ctx_set_shards(cftrt_ctx* ctx, int on);
+/* Per-tile lists for the primary rays (default on) - an EXTENSION like the grid: when the image is rendered in whole
+ * 32x8-pixel tiles (width a multiple of 32, height of 8), every render call first bins the bounding spheres of the
+ * listed primitives, widened for the lens, into the tiles whose rays can reach them (one pass over the primitives,
+ * ~40 us), and the level-0 launch scans a tile's list instead of the whole lists / instead of walking the grid.  The
+ * lists are conservative supersets and feed the same cull and exact evaluation: same image bit for bit; the switch
+ * exists for that comparison and for profiling.  Not used by cftrt_render_device_static (it would allocate) nor by
+ * the split pipeline. */
+int cftrt_ctx_set_tile_lists(cftrt_ctx* ctx, int on);
 /* Deep levels path by path (default on): once fewer than `below` rays are alive (0 keeps the current value,
  * default 2^20; the host looks every 4 levels) the remaining trace levels run in one launch in which every lane
  * follows one path to its end (k_trace_finish) instead of one launch per level.  Same image bit for bit; the switch

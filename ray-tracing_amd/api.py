@@ -365,6 +365,10 @@ class Device:
         of scenes committed afterwards.  Images are identical with any mode."""
         self.check(self.lib.cftrt_ctx_set_grid(self.h, int(mode), float(cells_per_prim)))
 
+    def set_tile_lists(self, on):
+        """Per-tile primitive lists for the primary rays of tiled frames (default on; same image either way)."""
+        self.check(self.lib.cftrt_ctx_set_tile_lists(self.h, int(bool(on))))
+
     def set_shards(self, on):
         """Big trace levels append through 8 counters into a segmented queue (default on); same image either way."""
         self.check(self.lib.cftrt_ctx_set_shards(self.h, int(bool(on))))

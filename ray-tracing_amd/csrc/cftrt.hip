@@ -32,9 +32,11 @@ struct cftrt_ctx {
   int shards = 1;         // 1: levels with >= 2^22 rays append through CFT_SHARDS counters into a segmented queue
   int finish = 1;         // 1: once few rays are alive the remaining levels run path by path in one launch (k_trace_finish)
   uint32_t finish_below = 1u << 20;
+  int tile_lists = 1;     // 1: primary rays of tiled frames scan per-tile primitive lists built per render call (k_tile_bin)
+  bool tiles_active = false;   // the lists in tile_off / tile_idx are those of the render call in progress
   int n_cu = 256;
   // grow-only workspace
-  DevBuf qa[2], qb[2], qc[2], h0[2], h1[2], ht[2], rad, pqa, pqb, pqc, pqd, counts, accum_tmp, misc;
+  DevBuf qa[2], qb[2], qc[2], h0[2], h1[2], ht[2], rad, pqa, pqb, pqc, pqd, counts, accum_tmp, misc, tile_rng, tile_cnt, tile_off, tile_idx;
   uint32_t* host_counts = nullptr;   // pinned
   std::vector<hipEvent_t> events;
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
@@ -214,7 +216,7 @@ void cftrt_ctx_destroy(cftrt_ctx* ctx) {
   if (ctx->comm) (void)cftrt_comm_destroy(ctx);
   DevBuf* bufs[] = {&ctx->qa[0], &ctx->qa[1], &ctx->qb[0], &ctx->qb[1], &ctx->qc[0], &ctx->qc[1], &ctx->h0[0],
                     &ctx->h0[1], &ctx->h1[0], &ctx->h1[1], &ctx->ht[0], &ctx->ht[1], &ctx->rad, &ctx->pqa, &ctx->pqb, &ctx->pqc,
-                    &ctx->pqd, &ctx->counts, &ctx->accum_tmp, &ctx->misc};
+                    &ctx->pqd, &ctx->counts, &ctx->accum_tmp, &ctx->misc, &ctx->tile_rng, &ctx->tile_cnt, &ctx->tile_off, &ctx->tile_idx};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
@@ -258,6 +260,12 @@ int cftrt_ctx_set_pipeline(cftrt_ctx* ctx, int split) {
 int cftrt_ctx_set_shards(cftrt_ctx* ctx, int on) {
   if (!ctx) return CFTRT_ERR_INVALID;
   ctx->shards = on ? 1 : 0;
+  return CFTRT_OK;
+}
+
+int cftrt_ctx_set_tile_lists(cftrt_ctx* ctx, int on) {
+  if (!ctx) return CFTRT_ERR_INVALID;
+  ctx->tile_lists = on ? 1 : 0;
   return CFTRT_OK;
 }
 
@@ -543,6 +551,7 @@ int cftrt_scene_commit(cftrt_scene* s) {
   std::vector<float4> gridSph;
   std::vector<float2> gridSphX;
   std::vector<uint32_t> gridTri;
+  std::vector<float4> boundF;
   struct { int n[3]; double lo[3], hi[3], cs[3], far; } G = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, 0};
   {
     const int nS = n_sphF_real, nM = (int)msph_gid.size(), nT = (int)triF_gid.size(), nP = nS + nM + nT;
@@ -567,6 +576,28 @@ int cftrt_scene_commit(cftrt_scene* s) {
         b.lo[k] = std::min(v[0][k], std::min(v[1][k], v[2][k]));
         b.hi[k] = std::max(v[0][k], std::max(v[1][k], v[2][k]));
       }
+    }
+    // bounding spheres of the listed primitives, in list order (the per-tile lists of the primary rays: k_tile_bin;
+    // also what the cone test of a tile list reads), with slack far above the f32 rounding of the stored values
+    boundF.resize((size_t)nP);
+    for (int i = 0; i < nS + nM; ++i) {
+      const double cl = std::sqrt(cen[3 * i] * cen[3 * i] + cen[3 * i + 1] * cen[3 * i + 1] + cen[3 * i + 2] * cen[3 * i + 2]);
+      boundF[i] = make_float4((float)cen[3 * i], (float)cen[3 * i + 1], (float)cen[3 * i + 2],
+                              (float)((rad[i] + 1e-6 * (cl + rad[i]) + 1e-7) * (1. + 1e-6)));
+    }
+    for (int i = 0; i < nT; ++i) {
+      const float4 p0 = triF[3 * i], e1 = triF[3 * i + 1], e2 = triF[3 * i + 2];
+      const double v[3][3] = {{p0.x, p0.y, p0.z}, {(double)p0.x + e1.x, (double)p0.y + e1.y, (double)p0.z + e1.z},
+                              {(double)p0.x + e2.x, (double)p0.y + e2.y, (double)p0.z + e2.z}};
+      double g[3], r2 = 0.;
+      for (int k = 0; k < 3; ++k) g[k] = (v[0][k] + v[1][k] + v[2][k]) / 3.;
+      for (int j = 0; j < 3; ++j) {
+        double d2 = 0.;
+        for (int k = 0; k < 3; ++k) d2 += (v[j][k] - g[k]) * (v[j][k] - g[k]);
+        r2 = std::max(r2, d2);
+      }
+      const double gl = std::sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]), r = std::sqrt(r2);
+      boundF[(size_t)nS + nM + i] = make_float4((float)g[0], (float)g[1], (float)g[2], (float)((r + 1e-6 * (gl + r) + 1e-7) * (1. + 1e-6)));
     }
     if (nG >= 64) {
       double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
@@ -679,6 +710,10 @@ int cftrt_scene_commit(cftrt_scene* s) {
   if ((rc = upload(s, gridSph, &D.gridSph))) return rc;
   if ((rc = upload(s, gridSphX, &D.gridSphX))) return rc;
   if ((rc = upload(s, gridTri, &D.gridTri))) return rc;
+  if (boundF.empty()) boundF.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
+  if ((rc = upload(s, boundF, &D.boundF))) return rc;
+  D.tile_off = nullptr;
+  D.tile_idx = nullptr;
   {   // list-ordered copies for the exact evaluation of candidates (scene_dev.h)
     std::vector<double> lsD(4 * sphF_gid.size()), lmD(8 * msph_gid.size());
     std::vector<int4> listRec;
@@ -936,7 +971,9 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
   // instances: with / without the moving-sphere and triangle lists, with / without the grid walk
   // (primary rays of a scene whose lists are short take the cone cull, or at worst the lists: the instance without
   // the walk has the registers for 4 rays per lane without spills)
-  const bool walk = S.grid_mode && (level > 0 || S.grid_mode == 2);
+  // (with per-tile lists the primary rays of long-list scenes take them instead of the walk)
+  const bool tiles = gen && gen->tiled && S.tile_off && (R == 1 || R == 2 || R == 4);
+  const bool walk = S.grid_mode && (level > 0 || (S.grid_mode == 2 && !tiles));
   if (walk) { if (lean) { CFT_LAUNCH_R(4) } else { CFT_LAUNCH_R(7) } }
   else      { if (lean) { CFT_LAUNCH_R(0) } else { CFT_LAUNCH_R(3) } }
 #undef CFT_LAUNCH_R
@@ -1083,6 +1120,49 @@ static int bufs_from_static(cftrt_ctx* ctx, const SceneDev& S, uint32_t P, PassB
   return CFTRT_OK;
 }
 
+// Per-tile primitive lists for the primary rays of this render call (kernels.h, k_tile_bin): count, prefix, fill.
+// One host round trip for the total (the index buffer is sized by it); ~40 us per call.  Leaves ctx->tiles_active false
+// (the frame then renders as before) when the frame is not tiled, the lens is wide against the focus distance, or the
+// scene lists fewer primitives than one round of the cone test handles anyway.
+static int build_tile_lists(cftrt_scene* s, const CamDev& C, const cftrt_camera* cam) {
+  cftrt_ctx* ctx = s->ctx;
+  ctx->tiles_active = false;
+  const SceneDev& S = s->dev;
+  const uint32_t n = (uint32_t)(S.n_sphF + S.n_msph + S.n_triF);
+  if (!ctx->tile_lists || ctx->split || n < 64 || C.width % 32u || C.height % 8u) return CFTRT_OK;
+  const uint32_t ntx = C.width / 32u, nty = C.height / 8u, nt = ntx * nty;
+  if (ntx > 65535u || nty > 65535u) return CFTRT_OK;
+  {   // lens radius against the distance of the viewport plane (k_tile_bin divides by 1 - a / fd)
+    const double lu = std::sqrt(cam->up[0] * cam->up[0] + cam->up[1] * cam->up[1] + cam->up[2] * cam->up[2]);
+    const double ls = std::sqrt(cam->sight[0] * cam->sight[0] + cam->sight[1] * cam->sight[1] + cam->sight[2] * cam->sight[2]);
+    const double fd = cam->focus_dist * ls;   // (up to the tilt of a non-orthogonal `up`: a factor the 1/8 absorbs)
+    if (!(fd > 0.) || !(0.5 * std::fabs(cam->aperture) * (1. + lu) * 1.0001 < 0.125 * fd)) return CFTRT_OK;
+  }
+  int rc;
+  if ((rc = ensure(ctx, ctx->tile_rng, (size_t)n * sizeof(TileRange)))) return rc;
+  if ((rc = ensure(ctx, ctx->tile_cnt, (size_t)nt * 4))) return rc;
+  if ((rc = ensure(ctx, ctx->tile_off, (size_t)(nt + 1) * 4))) return rc;
+  hipStream_t st = ctx->stream;
+  HIP_TRY(ctx, hipMemsetAsync(ctx->tile_cnt.p, 0, (size_t)nt * 4, st));
+  const uint32_t g = (uint32_t)std::min<uint64_t>(((uint64_t)n * 64 + CFT_BLOCK - 1) / CFT_BLOCK, (uint64_t)ctx->n_cu * 8);   // a wave per primitive
+  hipLaunchKernelGGL(k_tile_bin, dim3(g), dim3(CFT_BLOCK), 0, st, C, S.boundF, n, S.bcx, S.bcy, S.bcz, ntx, nty,
+                     (TileRange*)ctx->tile_rng.p, (uint32_t*)ctx->tile_cnt.p, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0);
+  hipLaunchKernelGGL(k_tile_prefix, dim3(1), dim3(CFT_BLOCK), 0, st, (uint32_t*)ctx->tile_cnt.p, nt, (uint32_t*)ctx->tile_off.p);
+  uint32_t total = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&total, (uint32_t*)ctx->tile_off.p + nt, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  if ((uint64_t)total * 4 > (1ull << 30)) return CFTRT_OK;   // (a scene wrapped around the camera: not worth a GiB of lists)
+  if ((rc = ensure(ctx, ctx->tile_idx, std::max<size_t>((size_t)total * 4, 256)))) return rc;
+  hipLaunchKernelGGL(k_tile_bin, dim3(g), dim3(CFT_BLOCK), 0, st, C, S.boundF, n, S.bcx, S.bcy, S.bcz, ntx, nty,
+                     (TileRange*)ctx->tile_rng.p, (uint32_t*)ctx->tile_cnt.p, (const uint32_t*)ctx->tile_off.p,
+                     (uint32_t*)ctx->tile_idx.p, 1);
+  HIP_TRY(ctx, hipGetLastError());
+  if (getenv("CFTRT_DEBUG"))
+    fprintf(stderr, "cftrt tile lists: %u primitives, %u x %u tiles, %u entries (%.1f per tile)\n", n, ntx, nty, total, (double)total / nt);
+  ctx->tiles_active = true;
+  return CFTRT_OK;
+}
+
 // Renders path ids [pid_base, pid_base + P) (P = npix * nsamples) into the radiance buffer and, when
 // accum_dev != null, resolves them into accum_dev.
 static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t P, uint32_t nsamples, uint32_t npix,
@@ -1115,6 +1195,10 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
 
   const int tiled = (C.width % 32u == 0 && C.height % 8u == 0 && npix == C.width * C.height && P % npix == 0 && pid_base % npix == 0) ? 1 : 0;
   const GenArgs gen{C, jitter, tiled};
+  if (tiled && ctx->tiles_active && !ctx->split && !use_static) {
+    S.tile_off = (const uint32_t*)ctx->tile_off.p;
+    S.tile_idx = (const uint32_t*)ctx->tile_idx.p;
+  }
   if (ctx->split) {   // the fused pipeline generates inside its level-0 launch
     if (tm.begin(CLS_GEN)) return fail(ctx, CFTRT_ERR_HIP, "hipEventCreate failed");
     hipLaunchKernelGGL(k_generate, dim3(grid_for(ctx, P, 16)), dim3(CFT_BLOCK), 0, st_, C, pid_base, P, k0, k1, jitter, tiled, q[0]);
@@ -1258,15 +1342,18 @@ static int render_impl(cftrt_scene* s, const cftrt_camera* cam, uint32_t width, 
   double ms[CLS_N] = {0};
   uint32_t nl[CLS_N] = {0};
   HIP_TRY(ctx, hipEventRecord(ctx->ev_t0, ctx->stream));
+  if (!use_static && spp_end > spp_begin)   // (allocates: not in the call that must not)
+    if (int rc = build_tile_lists(s, C, cam)) return rc;
   for (uint32_t sb = spp_begin; sb < spp_end;) {
     uint32_t ns = (uint32_t)std::min<uint64_t>(spp_pass, spp_end - sb);
     uint64_t pid_base = (uint64_t)sb * npix;
     int rc = run_pass(s, C, pid_base, (uint32_t)(npix * ns), ns, (uint32_t)npix, max_depth, seed, 1, accum_dev, &st, tm,
                       use_static);
-    if (rc) return rc;
+    if (rc) { ctx->tiles_active = false; return rc; }
     sb += ns;
     tm.collect(ms, nl);   // run_pass has synchronised: fold this pass's kernel spans
   }
+  ctx->tiles_active = false;
   HIP_TRY(ctx, hipEventRecord(ctx->ev_t1, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   float msT = 0.f;

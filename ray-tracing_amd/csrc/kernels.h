@@ -791,14 +791,70 @@ __device__ __forceinline__ void scan_mtris(const SceneDev& S, RayPack<R, NS>& P,
   }
 }
 
+// ---- per-tile lists (primary rays of the default pipeline; k_tile_bin below builds them per render call).
+// A wave of the level-0 launch holds 64 R consecutive queue slots = pixels of ONE 32x8 tile and one sample, so instead
+// of putting every listed primitive through the cone test (scan_spheres_culled: n / 64 rounds per wave, which is what
+// made the grid walk the cheaper way for primary rays above 4 096 primitives) it reads the tile's list: the primitives
+// whose bounding sphere, widened for the lens, meets the tile's pyramid.  The list is a conservative superset of what
+// any ray of the tile can hit, so everything downstream - cone test (when the bundle is narrow), per-ray cull,
+// candidate sets, exact evaluation - is what the full scan would do for those primitives, and the image is the same
+// bit for bit (tests: tile lists on / off).  n0 .. n1 = the tile's range in S.tile_idx.
+template <int R, int NS, int LISTS>
+__device__ __forceinline__ void scan_tile_list(const SceneDev& S, RayPack<R, NS>& P, const Bundle& B, bool narrow,
+                                               uint32_t n0, uint32_t n1) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const int nS = S.n_sphF, nSM = S.n_sphF + S.n_msph;
+  for (uint32_t s0 = n0; s0 < n1; s0 += 64u) {
+    int idx = -1;
+    bool pass = false;
+    if (s0 + lane < n1) {
+      idx = (int)S.tile_idx[s0 + lane];
+      pass = true;
+      if (narrow) {
+        const float4 b = S.boundF[idx];
+        pass = bundle_reaches(B, b.x, b.y, b.z, b.w);
+      }
+    }
+    unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+    while (m) {
+      const int src = (int)__builtin_ctzll(m);
+      m &= m - 1ull;
+      const int id = __builtin_amdgcn_readlane(idx, src);   // wave-uniform: the primitive comes through scalar loads
+      if (!(LISTS & 3) || id < nS) {
+        const v4f sp = AS_CONST(c_f4p, S.sphF)[id];
+        scan_sphere<R, NS>(S, P, v2f{sp[0], sp[1]}, v2f{sp[2], sp[3]}, AS_CONST(c_f32p, S.sphR2)[id], id);
+      } else if ((LISTS & 1) && id < nSM) {
+        const v4f sb = AS_CONST(c_f4p, S.msphB)[id - nS];
+        scan_msphere<R, NS>(S, P, v2f{sb[0], sb[1]}, v2f{sb[2], sb[3]}, id - nS);
+      } else if (LISTS & 2) {
+        c_f4p tp = AS_CONST(c_f4p, S.triF);
+        const int t = id - nSM;
+        const v4f a = tp[3 * t], b = tp[3 * t + 1], cc = tp[3 * t + 2];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const float tlo = tri_lower_bound(S, 0.25f * PK(P, o4x, r), 0.25f * PK(P, o4y, r), 0.25f * PK(P, o4z, r), PK(P, dx, r),
+                                            PK(P, dy, r), PK(P, dz, r), mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z),
+                                            mk3(cc.x, cc.y, cc.z), P.U[r]);
+          if (tlo >= 0.0f) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) cand_insert(P.c[k][r], tlo, id);
+          }
+        }
+      }
+    }
+  }
+}
+
 // f32 scan of every non-precise primitive for R rays (indices into [sphF | msph | triF | mtri]).
 // part / nparts (wave-uniform): this wave scans the part-th slice of each list (nparts = 1: all of it).
 // WCULL: try the wave-level cull first (the R-rays-per-lane kernels; every lane of the wave must be active).
 // LISTS (compile time): 1 = the scene may hold moving spheres, 2 = triangles, 4 = the scene has a grid and the ctx
 // uses it; a scene of static spheres only, or a pass on the plain lists, runs kernels without the other code (and
 // its registers).
+// tile >= 0 (level 0 of the default pipeline, with S.tile_off set): the wave's rays are pixels of that tile, and its
+// list stands for the static / moving spheres and static triangles.
 template <int R, int NS, bool WCULL = false, int LISTS = 3>
-__device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P, int part = 0, int nparts = 1) {
+__device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P, int part = 0, int nparts = 1, int tile = -1) {
   const int n4_all = (S.n_sphF + 3) >> 2;
   const int lo4 = n4_all * part / nparts, hi4 = n4_all * (part + 1) / nparts;
   Bundle B;
@@ -866,6 +922,14 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P,
     return;
   }
   if (LISTS & 8) return;   // (not reached)
+  if (WCULL && !(LISTS & 8) && tile >= 0) {
+    const uint32_t n0 = AS_CONST(const uint32_t __attribute__((address_space(4)))*, S.tile_off)[tile];
+    const uint32_t n1 = AS_CONST(const uint32_t __attribute__((address_space(4)))*, S.tile_off)[tile + 1];
+    if (!S.wave_cull) B = wave_bundle<R, NS>(P);   // (B.live only; the cone filter stays off with the switch)
+    if (B.live) scan_tile_list<R, NS, LISTS>(S, P, B, cull, n0, n1);
+    if (LISTS & 2) scan_mtris<R, NS>(S, P, S.n_sphF + S.n_msph + S.n_triF, part, nparts);
+    return;
+  }
   if (cull) {
     scan_spheres_culled<R, NS>(S, P, B, lo4 << 2, min(hi4 << 2, S.n_sphF));
   } else {
@@ -1206,6 +1270,134 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_generate(CamDev C, uint64_t pid_b
                                                         uint32_t k1, int jitter, int tiled, QueueDev q) {
   for (uint32_t i = blockIdx.x * CFT_BLOCK + threadIdx.x; i < n; i += gridDim.x * CFT_BLOCK)
     generate_slot(C, pid_base, i, k0, k1, jitter, tiled, q);
+}
+
+// ------------------------------------------------------------------ per-tile lists for the primary rays
+// Which 32x8-pixel tiles can a primitive's bounding sphere (c, r) be hit from?  A primary ray runs from a lens point o,
+// |o - pos| <= a, through a viewport point F = tl + fw pw - fh ph (primary_ray above).  With the pinhole ray
+// P(s) = pos + s (F - pos), the real ray is X(s) = P(s) + (1 - s)(o - pos): within a |1 - s| of the pinhole ray at the
+// same s, and s = depth / fd (depth along the viewport normal g, fd = (tl - pos).g; the lens lies in the plane
+// through pos spanned by right and up, so o has depth 0).  X can touch the sphere only where the depth is at most
+// z + rho, so the pinhole ray passes within
+//     rho = (r + a (1 + z / fd)) / (1 - a / fd)        (z = depth of c; solves rho = r + a (1 + (z + rho) / fd))
+// of c.  The pinhole rays of tile column tx lie between the planes through pos that contain the viewport lines
+// fw = 32 tx - 0.5 and fw = 32 (tx + 1) - 0.5 (pixel jitter is +-0.5); likewise the rows.  A sphere wholly in front of the
+// camera meets that wedge only if it is not wholly on the far side of either plane: two signed plane distances
+// against rho per column and row.  Spheres that reach behind the lens plane go to every tile; spheres wholly behind it
+// to none (rays only go forward).  All in f64 from the f32 camera constants the generation uses, with slack (1e-4 rho,
+// 1e-5 of the distances involved, 0.01 + rounding pixels on the boundaries) far above the f32 rounding of the rays.
+struct TileRange { uint16_t tx0, tx1, ty0, ty1; };   // inclusive; tx0 > tx1: no tile
+
+// One WAVE per primitive: the lanes share out the column and row boundaries (two plane tests each, no square root:
+// d >= -rho  <=>  N.v >= 0 or (N.v)^2 <= rho^2 |N|^2), ballots give the first and last column / row, then the lanes
+// share out the tiles of the range.  pass 0: ranges and per-tile counts; pass 1 (after the prefix sum): the lists.
+__global__ __launch_bounds__(CFT_BLOCK) void k_tile_bin(CamDev C, const float4* boundF, uint32_t n, float bcx, float bcy,
+                                                        float bcz, uint32_t ntx, uint32_t nty, TileRange* ranges,
+                                                        uint32_t* cnt, const uint32_t* off, uint32_t* idx, int pass) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (blockIdx.x * CFT_BLOCK + threadIdx.x) >> 6, nwaves = (gridDim.x * CFT_BLOCK) >> 6;
+  const d3 pos = d3{(double)C.px, (double)C.py, (double)C.pz};
+  const d3 A = d3{(double)C.tlx, (double)C.tly, (double)C.tlz} - pos;
+  const d3 pw = d3{(double)C.pwx, (double)C.pwy, (double)C.pwz}, ph = d3{(double)C.phx, (double)C.phy, (double)C.phz};
+  d3 g = dunit(dcross(pw, ph));
+  if (ddot(A, g) < 0.) g = d3{-g.x, -g.y, -g.z};
+  const double fd = ddot(A, g);
+  // |rdx right + rdy up| <= a * (largest singular value of [right up]) for (rdx, rdy) in the disk of radius a
+  const double rr = (double)C.rx * C.rx + (double)C.ry * C.ry + (double)C.rz * C.rz;
+  const double uu = (double)C.ux * C.ux + (double)C.uy * C.uy + (double)C.uz * C.uz;
+  const double ru = (double)C.rx * C.ux + (double)C.ry * C.uy + (double)C.rz * C.uz;
+  const double tr = rr + uu, det = rr * uu - ru * ru;
+  const double a = (double)C.lens_radius * sqrt(0.5 * (tr + sqrt(fmax(tr * tr - 4. * det, 0.)))) * 1.0001;
+  const double lpos = sqrt(ddot(pos, pos));
+  const double lpw = sqrt(ddot(pw, pw)), lph = sqrt(ddot(ph, ph));
+  const double ltl = sqrt((double)C.tlx * C.tlx + (double)C.tly * C.tly + (double)C.tlz * C.tlz);
+  const double mp = 0.01 + 32. * 5.97e-8 * (ltl + lpos + C.width * lpw + C.height * lph) / fmin(lpw, lph);
+  for (uint32_t i = wave; i < n; i += nwaves) {
+    TileRange t{1, 0, 1, 0};
+    if (pass == 0) {
+      const float4 b = boundF[i];
+      const d3 v = d3{(double)b.x + (double)bcx, (double)b.y + (double)bcy, (double)b.z + (double)bcz} - pos;
+      const double z = ddot(v, g), lv = sqrt(ddot(v, v));
+      double rho = ((double)b.w + a * (1. + fmax(z, 0.) / fd)) / (1. - a / fd);   // (the host only bins when a < fd / 8)
+      rho = rho * 1.0001 + 1e-5 * (1. + lv + lpos);
+      const double rho2 = rho * rho;
+      if (z + rho <= 0.) {
+        // wholly behind the lens plane: no tile
+      } else if (z - rho <= 1e-6 * fd) {
+        t = TileRange{0, (uint16_t)(ntx - 1), 0, (uint16_t)(nty - 1)};
+      } else {
+        // not_below(N): c is not farther than rho on the negative side of the plane with normal N through pos
+        auto not_below = [&](d3 N) { const double d = ddot(N, v); return d >= 0. || d * d <= rho2 * ddot(N, N); };
+        uint32_t x0 = 0xFFFFFFFFu, x1 = 0u, y0 = 0xFFFFFFFFu, y1 = 0u;
+        bool anyx = false, anyy = false;
+        for (uint32_t k0 = 0; k0 < ntx; k0 += 64u) {
+          const uint32_t tx = k0 + lane;
+          bool ok = false;
+          if (tx < ntx) {
+            // column tx lies between the planes at fw = 32 tx - 0.5 and 32 (tx + 1) - 0.5 (+- the margin); a plane's
+            // normal (A + fw pw) x ph is turned towards growing fw
+            d3 NL = dcross(A + pw * (32. * tx - 0.5 - mp), ph), NR = dcross(A + pw * (32. * (tx + 1) - 0.5 + mp), ph);
+            if (ddot(NL, pw) < 0.) NL = d3{-NL.x, -NL.y, -NL.z};
+            if (ddot(NR, pw) > 0.) NR = d3{-NR.x, -NR.y, -NR.z};   // (turned towards falling fw: "not right of it")
+            ok = not_below(NL) && not_below(NR);
+          }
+          const unsigned long long m = __ballot(ok);
+          if (m) {
+            if (!anyx) x0 = k0 + (uint32_t)__builtin_ctzll(m);
+            x1 = k0 + 63u - (uint32_t)__builtin_clzll(m);
+            anyx = true;
+          }
+        }
+        for (uint32_t k0 = 0; k0 < nty && anyx; k0 += 64u) {
+          const uint32_t ty = k0 + lane;
+          bool ok = false;
+          if (ty < nty) {
+            d3 NT = dcross(A - ph * (8. * ty - 0.5 - mp), pw), NB = dcross(A - ph * (8. * (ty + 1) - 0.5 + mp), pw);
+            if (ddot(NT, ph) > 0.) NT = d3{-NT.x, -NT.y, -NT.z};   // towards growing fh = falling ph
+            if (ddot(NB, ph) < 0.) NB = d3{-NB.x, -NB.y, -NB.z};
+            ok = not_below(NT) && not_below(NB);
+          }
+          const unsigned long long m = __ballot(ok);
+          if (m) {
+            if (!anyy) y0 = k0 + (uint32_t)__builtin_ctzll(m);
+            y1 = k0 + 63u - (uint32_t)__builtin_clzll(m);
+            anyy = true;
+          }
+        }
+        if (anyx && anyy) t = TileRange{(uint16_t)x0, (uint16_t)x1, (uint16_t)y0, (uint16_t)y1};
+      }
+      if (lane == 0) ranges[i] = t;
+    } else {
+      t = ranges[i];
+    }
+    if (t.tx0 > t.tx1) continue;
+    const uint32_t w = (uint32_t)t.tx1 - t.tx0 + 1u, h = (uint32_t)t.ty1 - t.ty0 + 1u;
+    for (uint32_t j = lane; j < w * h; j += 64u) {
+      const uint32_t tile = (t.ty0 + j / w) * ntx + t.tx0 + j % w;
+      const uint32_t k = atomicAdd(&cnt[tile], 1u);
+      if (pass) idx[off[tile] + k] = i;
+    }
+  }
+}
+
+// Exclusive prefix sum of the tile counts (one block; a frame has ~8 k tiles): off[0 .. n], off[n] = total; clears cnt
+// for the second pass.
+__global__ __launch_bounds__(CFT_BLOCK) void k_tile_prefix(uint32_t* cnt, uint32_t n, uint32_t* off) {
+  __shared__ uint32_t part[CFT_BLOCK];
+  const uint32_t per = (n + CFT_BLOCK - 1) / CFT_BLOCK;
+  const uint32_t b = threadIdx.x * per, e = min(b + per, n);
+  uint32_t sum = 0;
+  for (uint32_t i = b; i < e; ++i) sum += cnt[i];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  uint32_t base = 0;
+  for (uint32_t t = 0; t < threadIdx.x; ++t) base += part[t];
+  for (uint32_t i = b; i < e; ++i) {
+    off[i] = base;
+    base += cnt[i];
+    cnt[i] = 0u;
+  }
+  if (threadIdx.x == CFT_BLOCK - 1) off[n] = base;
 }
 
 // ------------------------------------------------------------------ intersect
@@ -1872,7 +2064,10 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(SceneDev S, QueueD
       CFT_STAMP(2);
       // (the instances with the walk run the bounce levels, where nearly every wave walks the grid: without the
       // cone-cull code they keep more registers; the few narrow bundles there walk too)
-      scan_lists<R, NS, (LISTS & 4) == 0, (LISTS & 4) ? (LISTS | 8) : LISTS>(S, P);
+      int tile = -1;   // level 0 of a tiled frame with per-tile lists: the trip's 64 R slots are pixels of one 32x8 tile
+      if constexpr (GEN && (LISTS & 4) == 0 && 256 % (64 * R) == 0)
+        if (S.tile_off && gen.tiled) tile = (int)((wb % (gen.cam.width * gen.cam.height)) >> 8);
+      scan_lists<R, NS, (LISTS & 4) == 0, (LISTS & 4) ? (LISTS | 8) : LISTS>(S, P, 0, 1, tile);
       CFT_STAMP(3);
       isect_park<R, NS>(P, park);
     }

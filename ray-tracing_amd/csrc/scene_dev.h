@@ -42,8 +42,7 @@ struct SceneDev {
   const int* mtri_gid;
   int n_mtri;
   // ---- uniform grid over the lists above (an extension; 0 cells = none).  Cell (x, y, z) -> gridCell[(z*gny + y)*gnx + x]
-  const uint2* gridCell;  // x = (first sphere entry << 8) | count; y = (first triangle entry << 12) | (count << 4) | skip,
-                          // skip = for an empty cell, the distance in cells (largest over the axes, at most 15) to the nearest cell with an entry
+  const uint2* gridCell;  // x = (first sphere entry << 8) | count; y = (first triangle entry << 12) | (count << 4)
   const float4* gridSph;  // per entry: the sphF / msphB entry
   const float2* gridSphX; // per entry: (16 r^2, list index bits), read when the cull passes
   const uint32_t* gridTri;   // index into triF
@@ -79,6 +78,10 @@ struct SceneDev {
   const double* lsphD;    // light-shape spheres, 4 each
   const double* ltriD;    // light-shape triangles, 9 each
   int wave_cull;          // 1: the level kernels may cull spheres per wave (cftrt_ctx_set_wave_cull)
+  // ---- per-tile lists for the primary rays (set per render call; null: none) ----
+  const float4* boundF;   // every entry of [sphF | msph | triF]: a bounding sphere (centre relative to the scene centre, radius)
+  const uint32_t* tile_off;   // n_tiles + 1 offsets into tile_idx (tile = 32x8 pixels, row-major over the tiles)
+  const uint32_t* tile_idx;   // list indices (into [sphF | msph | triF]) of the primitives a ray of the tile may reach
   int any_motion;
   int prec_motion;        // some precise sphere moves
   int n_phong_mats;

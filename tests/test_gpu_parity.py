@@ -866,4 +866,51 @@ def test_grid_far_origins_go_to_the_rescan(rt):
         dev.set_grid(1)
     assert np.array_equal(out[0][0], out[1][0])
     assert list(out[0][1].rays_per_level[:depth]) == list(out[1][1].rays_per_level[:depth])
-    assert int(out[1][1].exact_rescan) > int(out[0][1].exact_rescan) + 1000   # the far bounce rays
+    assert int(out[1][1].exact_rescan) > int(out[0][1].exact_rescan) + 1000   # the far bounce rays@pytest.mark.gpu
+def test_tile_lists_are_exact(rt):
+    """Primary rays of a tiled frame (width % 32 == 0, height % 8 == 0) scan per-tile primitive lists built per render
+    call from the primitives' bounding spheres, the lens and the tile pyramids.  The lists must be supersets of what
+    any ray of the tile can hit: with them off (the cone cull over the whole lists, or the grid walk in S20k; both
+    checked against the oracle elsewhere) the image, the rays per level and the exact-evaluation counts are the same,
+    bit for bit - for the benchmark scenes, a wide lens, a camera INSIDE the scene looking along the ground (primitives
+    behind and around the lens), a tilted non-unit `up`, and a frame whose samples are cut into several passes."""
+    A = rt
+    cams = []
+    w, c = rt.scenes.s500(width=640, height=360)
+    cams.append(("s500", w, c, 640, 360, 4, 12))
+    w, c = rt.scenes.s20k(width=960, height=544)
+    cams.append(("s20k", w, c, 960, 544, 2, 12))
+    w, c = rt.scenes.scene_rs(width=800, height=496)
+    cams.append(("scene_rs motion blur", w, c, 800, 496, 3, 10))
+    w, _ = rt.scenes.s20k()
+    inside = (A.Camera.new((2.0, -1.0, 0.35), (-6.0, 5.0, 0.2)).with_focus_dist(3.0).with_aperture(0.3)
+              .with_fov(70.0).with_aspect(640 / 352).with_sample_rate(2))
+    cams.append(("s20k from inside, wide lens", w, inside, 640, 352, 2, 8))
+    w, _ = rt.scenes.s500()
+    tilted = (A.Camera.new((-9.0, 7.0, 1.0), (0.0, 0.0, 0.3)).with_focus_dist(8.0).with_aperture(0.05)
+              .with_fov(35.0).with_aspect(512 / 256).with_sample_rate(2))
+    cams.append(("s500 low camera", w, tilted, 512, 256, 2, 8))
+    w, c = rt.scenes.cornell_rs()
+    cams.append(("cornell (below the list threshold: lists stay off)", w, c, 384, 288, 4, 8))
+    dev = rt.default_device()
+    for name, world, cam, W, H, spp, depth in cams:
+        res = []
+        try:
+            for on in (0, 1):
+                dev.set_tile_lists(on)
+                res.append(world.render(cam.with_sample_rate(spp), W, H, depth, return_stats=True))
+            dev.set_workspace_limit(64 << 20)      # (the smallest limit: one to three samples per pass here)
+            res.append(world.render(cam.with_sample_rate(spp), W, H, depth, return_stats=True))
+        finally:
+            dev.set_tile_lists(1)
+            dev.set_workspace_limit(40 << 30)
+        (a0, s0), (a1, s1), (a2, s2) = res
+        assert np.array_equal(a0, a1), name
+        assert np.array_equal(a0, a2), name
+        assert list(s0.rays_per_level[:depth]) == list(s1.rays_per_level[:depth]) == list(s2.rays_per_level[:depth]), name
+        assert int(s0.rays) == int(s1.rays) and int(s0.exact_rescan) == int(s1.exact_rescan), name
+        if name in ("s500", "s20k"):
+            assert int(s2.passes) > 1, name
+
+
+
