@@ -42,6 +42,11 @@ if os.environ.get("CFTRT_GRID"):   # "mode[,cells_per_prim]" (0 = the plain list
     rt.default_device().set_grid(int(g[0]), float(g[1]) if len(g) > 1 else 0.0)
 if os.environ.get("CFTRT_TILE_LISTS"):
     rt.default_device().set_tile_lists(int(os.environ["CFTRT_TILE_LISTS"]))
+if os.environ.get("CFTRT_FINISH"):        # "on[,below]"
+    f = os.environ["CFTRT_FINISH"].split(",")
+    rt.default_device().set_finish(int(f[0]), int(f[1]) if len(f) > 1 else 0)
+if os.environ.get("CFTRT_VARIANT"):
+    rt.default_device().set_variant(int(os.environ["CFTRT_VARIANT"]))
 which = sys.argv[1:] or ["C1", "C2", "C2p", "C3", "C4", "C5", "cpu"]
 if "C1" in which:
     w, c = rt.scenes.scene_rs(); gpu("C1 scene.rs (motion blur on)", w, c, 800, 500, 50, 10)
