@@ -948,14 +948,12 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
     out_D = (uint32_t)((trips + CFT_SHARDS - 1) / CFT_SHARDS) * 64u * R;
     *out_D_io = out_D;
   }
-#define CFT_LAUNCH(RR, NN, LL)                                                                                              \
-  do {                                                                                                                      \
-    if (gen) hipLaunchKernelGGL((k_trace_level<RR, NN, LL, true>), dim3(g), dim3(CFT_BLOCK), dyn_lds, st, S, q, counts, level,     \
-                                max_depth, pid_base, k0, k1, role0, role1, qout, rad, pq, phong_counts, xstats, *gen, in_D,  \
-                                out_k, out_D);                                                                              \
-    else hipLaunchKernelGGL((k_trace_level<RR, NN, LL, false>), dim3(g), dim3(CFT_BLOCK), dyn_lds, st, S, q, counts, level,        \
-                            max_depth, pid_base, k0, k1, role0, role1, qout, rad, pq, phong_counts, xstats, no_gen, in_D,   \
-                            out_k, out_D);                                                                                  \
+  LevelArgs LA{S, q, counts, level, max_depth, pid_base, k0, k1, role0, role1, qout, rad, pq, phong_counts, xstats,
+               gen ? *gen : no_gen, in_D, out_k, out_D};
+#define CFT_LAUNCH(RR, NN, LL)                                                                                          \
+  do {                                                                                                                  \
+    if (gen) hipLaunchKernelGGL((k_trace_level<RR, NN, LL, true>), dim3(g), dim3(CFT_BLOCK), dyn_lds, st, LA);           \
+    else hipLaunchKernelGGL((k_trace_level<RR, NN, LL, false>), dim3(g), dim3(CFT_BLOCK), dyn_lds, st, LA);              \
   } while (0)
 #define CFT_LAUNCH_R(LL)                                                    \
   if (two_scans) {                                                        \

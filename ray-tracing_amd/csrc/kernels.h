@@ -1990,13 +1990,35 @@ __device__ __forceinline__ void wave_sort_rays(const SceneDev& S, const QueueDev
 // of loading it, and writes it to the queue (the 40 B a separate k_generate would write) for the slot loop after the
 // scan to read back; the writes drain under the scan.  A wave that sorts its rays first (long-list scenes, where the
 // primary rays walk the grid too) generates them into the queue before the sort and loads them like any other level.
+// The arguments of k_trace_level, as ONE struct at the start of the kernarg segment.  The kernel does not use its
+// parameter: each phase of a trip reads what it needs through the kernarg pointer (scalar loads that hit the scalar
+// cache), taken afresh so that the compiler cannot keep a value across phases.  Passed as ~110 separate dwords the
+// arguments were all loaded at the kernel's entry and, far more than the 100 SGPRs there are, lived in VGPR lanes:
+// 11 % of the kernel's instructions were v_readlane / v_writelane moves of them (28 % of the set-up blocks).
+struct LevelArgs {
+  SceneDev S;
+  QueueDev q;
+  uint32_t* counts;
+  uint32_t level, max_depth;
+  uint64_t pid_base;
+  uint32_t k0, k1, role0, role1;
+  QueueDev qout;
+  float4* radiance;
+  PhongQueueDev pq;
+  uint32_t* phong_counts;
+  uint32_t* stats;
+  GenArgs gen;
+  uint32_t in_D, out_k, out_D;
+};
+__device__ __forceinline__ const LevelArgs& level_args() {
+  typedef const LevelArgs __attribute__((address_space(4)))* P4;
+  P4 p = (P4)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));   // a fresh view: nothing loaded through an earlier one is known to be the same
+  return *(const LevelArgs*)p;
+}
+
 template <int R, int NS, int LISTS, bool GEN = false>
-__global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(SceneDev S, QueueDev q, uint32_t* counts, uint32_t level,
-                                                           uint32_t max_depth, uint64_t pid_base, uint32_t k0,
-                                                           uint32_t k1, uint32_t role0, uint32_t role1, QueueDev qout,
-                                                           float4* radiance, PhongQueueDev pq, uint32_t* phong_counts,
-                                                           uint32_t* stats, GenArgs gen, uint32_t in_D, uint32_t out_k,
-                                                           uint32_t out_D) {
+__global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(LevelArgs) {
   __shared__ float park[ParkLayout<NS>::WORDS * R][CFT_BLOCK];
   // (the 4-ray instances serve the primary rays, which are not sorted; their park already fills the 40 KB a block
   // may take at 4 blocks per CU)
@@ -2007,24 +2029,23 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(SceneDev S, QueueD
   // it mod out_k (out_k = 1: dense), which therefore receives at most ceil(trips / out_k) * 64 R rays <= out_D.
   uint32_t trips_to[CFT_SHARDS + 1];
   trips_to[0] = 0u;
+  {
+    const LevelArgs& A = level_args();
 #pragma unroll
-  for (int sh = 0; sh < CFT_SHARDS; ++sh)
-    trips_to[sh + 1] = trips_to[sh] + (AS_CONST(const uint32_t __attribute__((address_space(4)))*, counts)[sh * CFT_SHARD_STRIDE + level] + 64u * R - 1u) / (64u * R);
+    for (int sh = 0; sh < CFT_SHARDS; ++sh)
+      trips_to[sh + 1] = trips_to[sh] + (AS_CONST(const uint32_t __attribute__((address_space(4)))*, A.counts)[sh * CFT_SHARD_STRIDE + A.level] + 64u * R - 1u) / (64u * R);
+#ifdef CFT_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x == 0) g_walk_stats = A.level < 4u ? (unsigned long long*)(A.stats + 8 + 128 + 2) + 32 * A.level : nullptr;
+#endif
+  }
   const uint32_t stride = 64u;   // wave-contiguous slots, wave-uniform trip count (see k_intersect)
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t q_in_D = in_D;
-  const QueueDev q_all = q;
   uint32_t n = 0;   // slots of the current trip's segment
-  // bounce rays that will walk the grid are sorted by walk length inside the wave (primary rays take the cone cull)
-  const bool sorted = SORT && S.grid_mode && (level > 0 || S.grid_mode == 2);
   auto slot_index = [&](int r, uint32_t base) -> uint32_t {
     if constexpr (SORT) return ss.perm[r][threadIdx.x] == 0xFFFFu ? 0xFFFFFFFFu : base - (threadIdx.x & 63u) + ss.perm[r][threadIdx.x];
     else return base + r * 64u < n ? base + r * 64u : 0xFFFFFFFFu;
   };
   CFT_STAMP_DECL;
-#ifdef CFT_STAMPS
-  if (threadIdx.x == 0 && blockIdx.x == 0) g_walk_stats = level < 4u ? (unsigned long long*)(stats + 8 + 128 + 2) + 32 * level : nullptr;
-#endif
   for (uint32_t it = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (CFT_BLOCK / 64u) + (threadIdx.x >> 6)));
        it < trips_to[CFT_SHARDS]; it += gridDim.x * (CFT_BLOCK / 64u)) {
     uint32_t seg = 0;
@@ -2033,78 +2054,95 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(SceneDev S, QueueD
     uint32_t seg_trip0 = 0;
 #pragma unroll
     for (int sh = 1; sh < CFT_SHARDS; ++sh) seg_trip0 = seg == (uint32_t)sh ? trips_to[sh] : seg_trip0;
-    n = AS_CONST(const uint32_t __attribute__((address_space(4)))*, counts)[seg * CFT_SHARD_STRIDE + level];
-    const size_t qoff = (size_t)seg * q_in_D;
-    q = QueueDev{q_all.a + qoff, q_all.b + qoff, q_all.c + qoff};   // the segment, indexed from 0
     const uint32_t wb = (it - seg_trip0) * 64u * R;
     const uint32_t base = wb + lane;
-    CFT_STAMP(7);   // (loop overhead, and the time before the first trip)
-    if constexpr (GEN && SORT) {
-#pragma unroll 1
-      for (int r = 0; r < R; ++r)
-        if (base + r * stride < n) generate_slot(gen.cam, pid_base, base + r * stride, k0, k1, gen.jitter, gen.tiled, q);
-      // the wave reads its slots back in sorted order (other lanes' slots too), through the same L1
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-    CFT_STAMP(0);
-    if constexpr (SORT) {
-      if (sorted) {
-        wave_sort_rays<R>(S, q, n, base, ss.perm, ss.hist);
-      } else {
-#pragma unroll
-        for (int r = 0; r < R; ++r) ss.perm[r][threadIdx.x] = base + r * stride < n ? (uint16_t)(lane + r * stride) : (uint16_t)0xFFFFu;
-      }
-    }
-    CFT_STAMP(1);
+    QueueDev q;   // the trip's segment of the input queue, indexed from 0
     {
+      // ---- the rays of the trip: (generated,) sorted, set up, scanned, parked
+      const LevelArgs& A = level_args();
+      const SceneDev& S = A.S;
+      n = AS_CONST(const uint32_t __attribute__((address_space(4)))*, A.counts)[seg * CFT_SHARD_STRIDE + A.level];
+      const size_t qoff = (size_t)seg * A.in_D;
+      q = QueueDev{A.q.a + qoff, A.q.b + qoff, A.q.c + qoff};
+      CFT_STAMP(7);   // (loop overhead, and the time before the first trip)
+      if constexpr (GEN && SORT) {
+#pragma unroll 1
+        for (int r = 0; r < R; ++r)
+          if (base + r * stride < n) generate_slot(A.gen.cam, A.pid_base, base + r * stride, A.k0, A.k1, A.gen.jitter, A.gen.tiled, q);
+        // the wave reads its slots back in sorted order (other lanes' slots too), through the same L1
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
+      CFT_STAMP(0);
+      if constexpr (SORT) {
+        // bounce rays that will walk the grid are sorted by walk length inside the wave (primary rays take the cone cull)
+        if (S.grid_mode && (A.level > 0 || S.grid_mode == 2)) {
+          wave_sort_rays<R>(S, q, n, base, ss.perm, ss.hist);
+        } else {
+#pragma unroll
+          for (int r = 0; r < R; ++r) ss.perm[r][threadIdx.x] = base + r * stride < n ? (uint16_t)(lane + r * stride) : (uint16_t)0xFFFFu;
+        }
+      }
+      CFT_STAMP(1);
       RayPack<R, NS> P;
-      if constexpr (SORT) isect_setup<R, NS>(S, q, n, wb, stride, level, pid_base, k0, k1, role0, role1, P, park, ss.perm);
-      else isect_setup<R, NS>(S, q, n, base, stride, level, pid_base, k0, k1, role0, role1, P, park, nullptr, GEN ? &gen : nullptr);
+      {
+        const GenArgs gen = A.gen;
+        if constexpr (SORT) isect_setup<R, NS>(S, q, n, wb, stride, A.level, A.pid_base, A.k0, A.k1, A.role0, A.role1, P, park, ss.perm);
+        else isect_setup<R, NS>(S, q, n, base, stride, A.level, A.pid_base, A.k0, A.k1, A.role0, A.role1, P, park, nullptr, GEN ? &gen : nullptr);
+      }
       CFT_STAMP(2);
-      // (the instances with the walk run the bounce levels, where nearly every wave walks the grid: without the
-      // cone-cull code they keep more registers; the few narrow bundles there walk too)
-      int tile = -1;   // level 0 of a tiled frame with per-tile lists: the trip's 64 R slots are pixels of one 32x8 tile
-      if constexpr (GEN && (LISTS & 4) == 0 && 256 % (64 * R) == 0)
-        if (S.tile_off && gen.tiled) tile = (int)((wb % (gen.cam.width * gen.cam.height)) >> 8);
-      scan_lists<R, NS, (LISTS & 4) == 0, (LISTS & 4) ? (LISTS | 8) : LISTS>(S, P, 0, 1, tile);
+      {
+        // (the instances with the walk run the bounce levels, where nearly every wave walks the grid: without the
+        // cone-cull code they keep more registers; the few narrow bundles there walk too)
+        const LevelArgs& A2 = level_args();
+        const SceneDev& S2 = A2.S;
+        int tile = -1;   // level 0 of a tiled frame with per-tile lists: the trip's 64 R slots are pixels of one 32x8 tile
+        if constexpr (GEN && (LISTS & 4) == 0 && 256 % (64 * R) == 0)
+          if (S2.tile_off && A2.gen.tiled) tile = (int)((wb % (A2.gen.cam.width * A2.gen.cam.height)) >> 8);
+        scan_lists<R, NS, (LISTS & 4) == 0, (LISTS & 4) ? (LISTS | 8) : LISTS>(S2, P, 0, 1, tile);
+      }
       CFT_STAMP(3);
       isect_park<R, NS>(P, park);
     }
     CFT_STAMP(4);
     uint32_t alive_bits = 0;
-    // the slot's ray is re-read from the queue (HBM: the queue is far bigger than the caches); the next slot's
-    // loads are issued before this slot is processed
-    uint32_t inext = slot_index(0, base);
-    float4 an = q.a[inext < n ? inext : wb], bn = q.b[inext < n ? inext : wb];
-    float2 cn = q.c[inext < n ? inext : wb];
+    {
+      // ---- the slots one by one: exact evaluation, hit record, shading
+      const LevelArgs& A = level_args();
+      const SceneDev& S = A.S;
+      // the slot's ray is re-read from the queue (HBM: the queue is far bigger than the caches); the next slot's
+      // loads are issued before this slot is processed
+      uint32_t inext = slot_index(0, base);
+      float4 an = q.a[inext < n ? inext : wb], bn = q.b[inext < n ? inext : wb];
+      float2 cn = q.c[inext < n ? inext : wb];
 #pragma unroll 1
-    for (int r = 0; r < R; ++r) {
-      if (!(wb + r * stride < n)) break;   // wave-uniform: the whole wave stays together for isect_hit
-      const uint32_t i = inext;
-      const bool live = i < n;
-      const float4 a = an, b = bn;
-      const float2 c = cn;
-      {
-        inext = r + 1 < R ? slot_index(r + 1, base) : 0xFFFFFFFFu;
-        const uint32_t j = inext < n ? inext : wb;
-        an = q.a[j]; bn = q.b[j]; cn = q.c[j];
-      }
-      HitInRegisters hit;
-      isect_hit<NS>(S, live, r, 0, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.a0, &hit.b1, &hit.ta, &hit.mat_id);
-      hit.b0 = hit.a0;
-      if (NS == 2) {
-        double tb;
-        isect_hit<NS>(S, live, r, 1, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.b0, &hit.b1, &tb, &hit.mat_id);
-      }
-      f3 thr = mk3(b.z, b.w, c.x), npos, ndir;
-      const bool alive = live && shade_one(S, hit, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), &thr, __float_as_uint(c.y), level,
-                                           max_depth, pid_base, k0, k1, radiance, pq, phong_counts, &npos, &ndir);
-      if (alive) {   // the survivor takes over the slot's park words (path id: re-read from the queue below)
-        alive_bits |= 1u << r;
-        PARK(r, 0) = npos.x; PARK(r, 1) = npos.y; PARK(r, 2) = npos.z; PARK(r, 3) = ndir.x;
-        PARK(r, 4) = ndir.y; PARK(r, 5) = ndir.z; PARK(r, 6) = thr.x;  PARK(r, 7) = thr.y;
-        PARK(r, 8) = thr.z;
+      for (int r = 0; r < R; ++r) {
+        if (!(wb + r * stride < n)) break;   // wave-uniform: the whole wave stays together for isect_hit
+        const uint32_t i = inext;
+        const bool live = i < n;
+        const float4 a = an, b = bn;
+        const float2 c = cn;
+        {
+          inext = r + 1 < R ? slot_index(r + 1, base) : 0xFFFFFFFFu;
+          const uint32_t j = inext < n ? inext : wb;
+          an = q.a[j]; bn = q.b[j]; cn = q.c[j];
+        }
+        HitInRegisters hit;
+        isect_hit<NS>(S, live, r, 0, a.x, a.y, a.z, a.w, b.x, b.y, park, A.stats, &hit.a0, &hit.b1, &hit.ta, &hit.mat_id);
+        hit.b0 = hit.a0;
+        if (NS == 2) {
+          double tb;
+          isect_hit<NS>(S, live, r, 1, a.x, a.y, a.z, a.w, b.x, b.y, park, A.stats, &hit.b0, &hit.b1, &tb, &hit.mat_id);
+        }
+        f3 thr = mk3(b.z, b.w, c.x), npos, ndir;
+        const bool alive = live && shade_one(S, hit, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), &thr, __float_as_uint(c.y), A.level,
+                                             A.max_depth, A.pid_base, A.k0, A.k1, A.radiance, A.pq, A.phong_counts, &npos, &ndir);
+        if (alive) {   // the survivor takes over the slot's park words (path id: re-read from the queue below)
+          alive_bits |= 1u << r;
+          PARK(r, 0) = npos.x; PARK(r, 1) = npos.y; PARK(r, 2) = npos.z; PARK(r, 3) = ndir.x;
+          PARK(r, 4) = ndir.y; PARK(r, 5) = ndir.z; PARK(r, 6) = thr.x;  PARK(r, 7) = thr.y;
+          PARK(r, 8) = thr.z;
+        }
       }
     }
     CFT_STAMP(5);
@@ -2113,11 +2151,13 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(SceneDev S, QueueD
 #pragma unroll
     for (int r = 0; r < R; ++r) total += (uint32_t)__popcll(__ballot((alive_bits >> r) & 1u));
     if (total) {   // wave-uniform
+      const LevelArgs& A = level_args();
+      const QueueDev qout = A.qout;
       const uint32_t leader = (uint32_t)__ffsll((long long)__ballot(1)) - 1u;
       uint32_t wbase = 0;
-      const uint32_t oseg = out_k > 1u ? it % out_k : 0u;
-      if (lane == leader) wbase = atomicAdd(&counts[oseg * CFT_SHARD_STRIDE + level + 1], total);
-      wbase = __shfl(wbase, (int)leader) + oseg * out_D;
+      const uint32_t oseg = A.out_k > 1u ? it % A.out_k : 0u;
+      if (lane == leader) wbase = atomicAdd(&A.counts[oseg * CFT_SHARD_STRIDE + A.level + 1], total);
+      wbase = __shfl(wbase, (int)leader) + oseg * A.out_D;
 #pragma unroll 1
       for (int r = 0; r < R; ++r) {
         const unsigned long long m = __ballot((alive_bits >> r) & 1u);
@@ -2132,7 +2172,12 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(SceneDev S, QueueD
     }
     CFT_STAMP(6);
   }
-  CFT_STAMP_FLUSH(stats, level);
+#ifdef CFT_STAMPS
+  {
+    const LevelArgs& A = level_args();
+    CFT_STAMP_FLUSH(A.stats, A.level);
+  }
+#endif
 }
 
 // The same level step for launches that cannot fill the chip (the deep levels: 16 k - 300 k live rays against
