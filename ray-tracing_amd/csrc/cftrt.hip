@@ -1231,8 +1231,8 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
     }
     if (phong) {
       tm.begin(CLS_SHADOW);
-      hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(CFT_BLOCK), 0, st_, S, pq, phong_counts, level, pid_base, k0, k1, rad,
-                         xstats);
+      const ShadowArgs SA{S, pq, phong_counts, level, pid_base, k0, k1, rad, xstats};
+      hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(CFT_BLOCK), 0, st_, SA);
     }
     levels_run = level + 1;
     // every 4 levels (every 16 once the launches are latency-bound: a peek idles the GPU for ~35 us) look at the
@@ -1254,8 +1254,9 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
         // at most what the chip holds at once (lanes refill from the queue)
         if (tm.begin(CLS_ISECT)) return fail(ctx, CFTRT_ERR_HIP, "hipEventCreate failed");
         const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)ub + CFT_BLOCK - 1) / CFT_BLOCK, (uint64_t)ctx->n_cu * 8));
-        hipLaunchKernelGGL(k_trace_finish, dim3(blocks), dim3(CFT_BLOCK), 0, st_, S, q[outq], counts, level + 1, max_depth,
-                           pid_base, k0, k1, two_scans ? looked_role : nl, nl, two_scans ? 1 : 0, rad, xstats + 2, xstats, in_D);
+        const FinishArgs FA{S, q[outq], counts, level + 1, max_depth, pid_base, k0, k1, two_scans ? looked_role : nl, nl,
+                            two_scans ? 1 : 0, rad, xstats + 2, xstats, in_D};
+        hipLaunchKernelGGL(k_trace_finish, dim3(blocks), dim3(CFT_BLOCK), 0, st_, FA);
         levels_run = max_depth;
         break;
       }

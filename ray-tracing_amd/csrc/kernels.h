@@ -2010,12 +2010,14 @@ struct LevelArgs {
   GenArgs gen;
   uint32_t in_D, out_k, out_D;
 };
-__device__ __forceinline__ const LevelArgs& level_args() {
-  typedef const LevelArgs __attribute__((address_space(4)))* P4;
+template <typename T>
+__device__ __forceinline__ const T& kernel_args() {   // (the kernel's one parameter is a T: offset 0 of the segment)
+  typedef const T __attribute__((address_space(4)))* P4;
   P4 p = (P4)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(p));   // a fresh view: nothing loaded through an earlier one is known to be the same
-  return *(const LevelArgs*)p;
+  return *(const T*)p;
 }
+__device__ __forceinline__ const LevelArgs& level_args() { return kernel_args<LevelArgs>(); }
 
 template <int R, int NS, int LISTS, bool GEN = false>
 __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(LevelArgs) {
@@ -2296,11 +2298,25 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_tail(SceneDev S, QueueDe
 // is the same bit for bit (cftrt_ctx_set_finish toggles it; tested).
 // Rays traced per level are counted in LDS and added to counts[level] at the end (counts[level0] is already right).
 // Not for scenes with PhongModel materials (their hits go through k_shadow level by level).
-__global__ __launch_bounds__(CFT_BLOCK) void k_trace_finish(SceneDev S, QueueDev q, uint32_t* counts, uint32_t level0,
-                                                            uint32_t max_depth, uint64_t pid_base, uint32_t k0, uint32_t k1,
-                                                            uint32_t role0, uint32_t role1, int two_scans, float4* radiance,
-                                                            uint32_t* cursor, uint32_t* stats, uint32_t in_D) {
+struct FinishArgs {   // (one struct, read per phase through the kernarg pointer: see LevelArgs)
+  SceneDev S;
+  QueueDev q;
+  uint32_t* counts;
+  uint32_t level0, max_depth;
+  uint64_t pid_base;
+  uint32_t k0, k1, role0, role1;
+  int two_scans;
+  float4* radiance;
+  uint32_t* cursor;
+  uint32_t* stats;
+  uint32_t in_D;
+};
+__global__ __launch_bounds__(CFT_BLOCK) void k_trace_finish(FinishArgs) {
   __shared__ uint32_t hist[CFT_BLOCK / 64][CFTRT_MAX_LEVELS_DEV];
+  const FinishArgs& A0 = kernel_args<FinishArgs>();
+  uint32_t* const counts = A0.counts;
+  const uint32_t level0 = A0.level0, in_D = A0.in_D;
+  const QueueDev q = A0.q;
   // the input queue may be sharded: slot v of the concatenated segments sits at seg * in_D + (v - slots before seg)
   uint32_t slots_to[CFT_SHARDS + 1];
   slots_to[0] = 0u;
@@ -2316,6 +2332,7 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_trace_finish(SceneDev S, QueueDev
   const PhongQueueDev no_pq{nullptr, nullptr, nullptr, nullptr};
   while (true) {
     if (!drained) {   // wave-uniform
+      uint32_t* const cursor = kernel_args<FinishArgs>().cursor;
       const unsigned long long idle = __ballot(!have);
       if (idle) {
         const uint32_t cnt = (uint32_t)__popcll(idle);
@@ -2349,6 +2366,12 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_trace_finish(SceneDev S, QueueDev
         if (lane == (uint32_t)lead) hist[wave][lv] += (uint32_t)__popcll(m);
         todo &= ~m;
       }
+      const FinishArgs& A = kernel_args<FinishArgs>();
+      const SceneDev& S = A.S;
+      const uint64_t pid_base = A.pid_base;
+      const uint32_t k0 = A.k0, k1 = A.k1, role0 = A.role0, role1 = A.role1;
+      const int two_scans = A.two_scans;
+      uint32_t* const stats = A.stats;
       uint32_t wA = 0, wB = 0;
       if (S.any_motion) {
         const uint64_t pid = pid_base + lpid;
@@ -2373,7 +2396,10 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_trace_finish(SceneDev S, QueueDev
         hit.b1 = make_float4((float)p.z, nn.x, nn.y, nn.z);
       }
       f3 npos, ndir;
-      have = shade_one(S, hit, pos, dir, &thr, lpid, level, max_depth, pid_base, k0, k1, radiance, no_pq, nullptr, &npos, &ndir);
+      {
+        const FinishArgs& A2 = kernel_args<FinishArgs>();
+        have = shade_one(A2.S, hit, pos, dir, &thr, lpid, level, A2.max_depth, A2.pid_base, A2.k0, A2.k1, A2.radiance, no_pq, nullptr, &npos, &ndir);
+      }
       pos = npos; dir = ndir;
       level += 1;
     }
@@ -2387,12 +2413,28 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_trace_finish(SceneDev S, QueueDev
 // one lane = one Phong hit; loops over the lights (basic.rs:57-94).  Every (hit, light) pair scans
 // one ray against the world: the mirror ray (sky / shape lights: `looked`, then `is_in_shadow` on the
 // same ray) or the ray towards the light (point / parallel lights).
-__global__ __launch_bounds__(CFT_BLOCK) void k_shadow(SceneDev S, PhongQueueDev pq, const uint32_t* phong_counts,
-                                                      uint32_t level, uint64_t pid_base, uint32_t k0, uint32_t k1,
-                                                      float4* radiance, uint32_t* stats) {
-  uint32_t n = phong_counts[level];
-  uint32_t nl = (uint32_t)S.n_lights;
+struct ShadowArgs {   // (one struct, read per phase through the kernarg pointer: see LevelArgs)
+  SceneDev S;
+  PhongQueueDev pq;
+  const uint32_t* phong_counts;
+  uint32_t level;
+  uint64_t pid_base;
+  uint32_t k0, k1;
+  float4* radiance;
+  uint32_t* stats;
+};
+__global__ __launch_bounds__(CFT_BLOCK) void k_shadow(ShadowArgs) {
+  const ShadowArgs& A0 = kernel_args<ShadowArgs>();
+  const uint32_t n = A0.phong_counts[A0.level];
+  const uint32_t nl = (uint32_t)A0.S.n_lights;
+  const uint32_t level = A0.level;
   for (uint32_t i = blockIdx.x * CFT_BLOCK + threadIdx.x; i < n; i += gridDim.x * CFT_BLOCK) {
+    const ShadowArgs& A = kernel_args<ShadowArgs>();
+    const SceneDev& S = A.S;
+    const PhongQueueDev pq = A.pq;
+    const uint64_t pid_base = A.pid_base;
+    const uint32_t k0 = A.k0, k1 = A.k1;
+    uint32_t* const stats = A.stats;
     float4 a = pq.a[i], b = pq.b[i], c = pq.c[i];
     uint2 dd = pq.d[i];
     f3 p = mk3(a.x, a.y, a.z), nrm = mk3(a.w, b.x, b.y), dout = mk3(b.z, b.w, c.x);
@@ -2447,7 +2489,7 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_shadow(SceneDev S, PhongQueueDev 
       sum = madd3(sum, lcol, inten * w);
     }
     f3 outc = mk3(m.p1 * sum.x * m.r, m.p1 * sum.y * m.g, m.p1 * sum.z * m.b);   // kd * c * color
-    radiance[dd.x] = make_float4(thr.x * outc.x, thr.y * outc.y, thr.z * outc.z, 0.f);
+    kernel_args<ShadowArgs>().radiance[dd.x] = make_float4(thr.x * outc.x, thr.y * outc.y, thr.z * outc.z, 0.f);
   }
 }
 
