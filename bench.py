@@ -191,7 +191,7 @@ def main():
     elapsed = time.perf_counter() - t0
     stats = [s for s in stats if s is not None]   # (a rank with an empty sample range rendered nothing)
 
-    # N = 1 only: the same frame with the wave cull and the grid off, i.e. the reference's plain linear scan, where
+    # N = 1 only: the same frame with the wave cull, the grid and the per-tile lists off, i.e. the reference's plain linear scan, where
     # every ray tests every sphere and the algorithmic flops of SURVEY 8d ARE the executed ones.  This leg, timed live
     # with the library's HIP events, is what `roofline.achieved` / `frac` report: it is the only reading in which the
     # flop count bounds the kernel.  The headline `value` above is the default path (cull + grid), which skips most of
@@ -200,6 +200,7 @@ def main():
     if world_size == 1 and not args.no_plain_scan and not split:
         dev.set_grid(0)
         dev.set_wave_cull(0)
+        dev.set_tile_lists(0)
         try:
             step()
             fence()
@@ -210,6 +211,7 @@ def main():
         finally:
             dev.set_grid(1)
             dev.set_wave_cull(1)
+            dev.set_tile_lists(1)
         pms = sum(x.ms_intersect for x in ps)
         pach = sum(x.flops for x in ps) / (pms * 1e-3) / 1e12
         pl = sum(int(x.launches_intersect) for x in ps)

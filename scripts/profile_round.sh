@@ -10,7 +10,7 @@ mkdir -p $out
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o p -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-plain-scan > $out/bench_under_rocprof.json
 cp $out/stats/p_kernel_stats.csv $out/kernel_stats.csv
 python3 scripts/level_times.py $out/stats > $out/level_times.txt
-CFTRT_GRID=0 CFTRT_WAVE_CULL=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_plain -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-plain-scan > $out/bench_plain_scan_under_rocprof.json
+CFTRT_GRID=0 CFTRT_WAVE_CULL=0 CFTRT_TILE_LISTS=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_plain -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-plain-scan > $out/bench_plain_scan_under_rocprof.json
 cp $out/stats_plain/p_kernel_stats.csv $out/kernel_stats_plain_scan.csv
 timeout -k 10 400 python3 bench.py > $out/bench.json
 PMC_WARMUP=1 bash scripts/pmc_pass.sh ${tag}_sq 0 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE
