@@ -1211,11 +1211,16 @@ struct CamDev {   // viewport constants of Camera::emit_rays (ray.rs:112-118), c
   uint32_t width, height;
 };
 
-// pix = pid mod (width * height) when the caller knows it (k_generate's tiled order), 0xFFFFFFFF otherwise.
+// pix = pid mod (width * height) when the caller knows it (k_generate's tiled order), 0xFFFFFFFF otherwise; (pw_, ph_) =
+// the pixel's column and row when the caller knows them too (no division then).
 __device__ __forceinline__ void primary_ray(const CamDev& C, uint64_t pid, uint32_t k0, uint32_t k1, int jitter,
-                                            f3* pos, f3* dir, uint32_t pix = 0xFFFFFFFFu) {
-  if (pix == 0xFFFFFFFFu) pix = (uint32_t)(pid % ((uint64_t)C.width * C.height));   // (a 64-bit division)
-  uint32_t w = pix % C.width, h = pix / C.width;   // image index h*WIDTH + w (scene.rs:97)
+                                            f3* pos, f3* dir, uint32_t pix = 0xFFFFFFFFu, uint32_t pw_ = 0xFFFFFFFFu,
+                                            uint32_t ph_ = 0u) {
+  uint32_t w = pw_, h = ph_;
+  if (pw_ == 0xFFFFFFFFu) {
+    if (pix == 0xFFFFFFFFu) pix = (uint32_t)(pid % ((uint64_t)C.width * C.height));   // (a 64-bit division)
+    w = pix % C.width; h = pix / C.width;   // image index h*WIDTH + w (scene.rs:97)
+  }
   float urw = 0.5f, urh = 0.5f, uth = 0.0f, ur = 0.0f;
   if (jitter) {
     u4 r = philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), CFT_LEVEL_CAMERA, CFT_PURPOSE_CAMERA, k0, k1);
@@ -1243,11 +1248,21 @@ struct GenArgs {   // level-0 launches that generate their own rays (k_trace_lev
 // through 32x8-pixel tiles, so that the 256 (or 128) consecutive slots a wave of the level kernels takes are a
 // compact pixel block: their primary rays form a narrow bundle, which the wave-level cull (wave_bundle) uses.
 // Otherwise lp = i (row-major).  The order of the queue never affects the image: radiance is stored by lp.
+// th (optional, tiled frames): the sample and the tile the slot belongs to, worked out once per trip by the caller (a
+// trip's slots are pixels of one tile and one sample); without it they come out of i by three divisions per lane.
+struct TileHint { uint32_t smp, tx, ty, slot0; };   // slot0 = the queue slot of the tile's first pixel in that sample; 0xFFFFFFFF: no hint
+#define CFT_NO_TILE_HINT TileHint{0u, 0u, 0u, 0xFFFFFFFFu}
 __device__ __forceinline__ void generate_slot(const CamDev& C, uint64_t pid_base, uint32_t i, uint32_t k0, uint32_t k1,
                                               int jitter, int tiled, const QueueDev& q, float4* a_out = nullptr,
-                                              float4* b_out = nullptr, uint32_t* lp_out = nullptr) {
-  uint32_t lp = i, pix = 0xFFFFFFFFu;
-  if (tiled) {   // (pid_base is a multiple of npix here, so the pixel of path pid_base + lp is lp mod npix)
+                                              float4* b_out = nullptr, uint32_t* lp_out = nullptr, TileHint th = CFT_NO_TILE_HINT) {
+  uint32_t lp = i, pix = 0xFFFFFFFFu, pxw = 0xFFFFFFFFu, pxh = 0u;
+  if (tiled && th.slot0 != 0xFFFFFFFFu) {
+    const uint32_t wi = i - th.slot0;   // 0 .. 255 inside the tile
+    pxw = th.tx * 32u + (wi & 31u);
+    pxh = th.ty * 8u + (wi >> 5);
+    pix = pxh * C.width + pxw;
+    lp = th.smp * (C.width * C.height) + pix;
+  } else if (tiled) {   // (pid_base is a multiple of npix here, so the pixel of path pid_base + lp is lp mod npix)
     const uint32_t npix = C.width * C.height;
     const uint32_t smp = i / npix, j = i - smp * npix;
     const uint32_t t = j >> 8, wi = j & 255u, ntx = C.width >> 5;
@@ -1256,7 +1271,7 @@ __device__ __forceinline__ void generate_slot(const CamDev& C, uint64_t pid_base
     lp = smp * npix + pix;
   }
   f3 pos, dir;
-  primary_ray(C, pid_base + lp, k0, k1, jitter, &pos, &dir, pix);
+  primary_ray(C, pid_base + lp, k0, k1, jitter, &pos, &dir, pix, pxw, pxh);
   const float4 a = make_float4(pos.x, pos.y, pos.z, dir.x), b = make_float4(dir.y, dir.z, 1.0f, 1.0f);
   q.a[i] = a;
   q.b[i] = b;
@@ -1445,7 +1460,7 @@ __device__ __forceinline__ void isect_setup(const SceneDev& S, const QueueDev& q
                                             uint32_t stride, uint32_t level, uint64_t pid_base, uint32_t k0,
                                             uint32_t k1, uint32_t role0, uint32_t role1, RayPack<R, NS>& P,
                                             float (*park)[CFT_BLOCK], const uint16_t (*perm)[CFT_BLOCK] = nullptr,
-                                            const GenArgs* gen = nullptr) {
+                                            const GenArgs* gen = nullptr, TileHint th = CFT_NO_TILE_HINT) {
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     // (with perm, base is the wave's first ray)
@@ -1461,7 +1476,7 @@ __device__ __forceinline__ void isect_setup(const SceneDev& S, const QueueDev& q
     if (i < n) {
       float4 a, b;
       uint32_t lp = 0;
-      if (gen) generate_slot(gen->cam, pid_base, i, k0, k1, gen->jitter, gen->tiled, q, &a, &b, &lp);
+      if (gen) generate_slot(gen->cam, pid_base, i, k0, k1, gen->jitter, gen->tiled, q, &a, &b, &lp, th);
       else { a = q.a[i]; b = q.b[i]; }
       ox = a.x; oy = a.y; oz = a.z; dx = a.w; dy = b.x; dz = b.y;
       if (S.any_motion) {
@@ -2087,10 +2102,23 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(LevelArgs) {
       }
       CFT_STAMP(1);
       RayPack<R, NS> P;
-      {
-        const GenArgs gen = A.gen;
-        if constexpr (SORT) isect_setup<R, NS>(S, q, n, wb, stride, A.level, A.pid_base, A.k0, A.k1, A.role0, A.role1, P, park, ss.perm);
-        else isect_setup<R, NS>(S, q, n, base, stride, A.level, A.pid_base, A.k0, A.k1, A.role0, A.role1, P, park, nullptr, GEN ? &gen : nullptr);
+      if constexpr (SORT) {
+        isect_setup<R, NS>(S, q, n, wb, stride, A.level, A.pid_base, A.k0, A.k1, A.role0, A.role1, P, park, ss.perm);
+      } else if constexpr (GEN) {
+        // a tiled frame: the trip's slots are pixels of one tile of one sample - which ones, once for the wave
+        TileHint th = CFT_NO_TILE_HINT;
+        if (A.gen.tiled && 256 % (64 * R) == 0) {
+          const uint32_t npix = A.gen.cam.width * A.gen.cam.height, ntx = A.gen.cam.width >> 5;
+          const uint32_t wbu = (uint32_t)__builtin_amdgcn_readfirstlane((int)wb);
+          th.smp = wbu / npix;
+          const uint32_t t = (wbu - th.smp * npix) >> 8;
+          th.ty = t / ntx;
+          th.tx = t - th.ty * ntx;
+          th.slot0 = th.smp * npix + (t << 8);
+        }
+        isect_setup<R, NS>(S, q, n, base, stride, A.level, A.pid_base, A.k0, A.k1, A.role0, A.role1, P, park, nullptr, &A.gen, th);
+      } else {
+        isect_setup<R, NS>(S, q, n, base, stride, A.level, A.pid_base, A.k0, A.k1, A.role0, A.role1, P, park);
       }
       CFT_STAMP(2);
       {
