@@ -1284,7 +1284,7 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
     }
 #ifdef CFT_STAMPS
     if (getenv("CFTRT_STAMPS")) {
-      static const char* names[8] = {"gen", "sort", "setup", "scan", "park", "epilogue", "append", "other"};
+      static const char* names[8] = {"gen", "sort", "setup", "scan", "exact+hit", "shade", "append", "other"};
       for (uint32_t l = 0; l < 8 && l < levels_run; ++l) {
         const unsigned long long* sp = (const unsigned long long*)(hc + kStampWord) + 8 * l;
         unsigned long long tot = 0;

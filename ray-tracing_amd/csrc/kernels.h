@@ -2164,6 +2164,7 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(LevelArgs) {
           double tb;
           isect_hit<NS>(S, live, r, 1, a.x, a.y, a.z, a.w, b.x, b.y, park, A.stats, &hit.b0, &hit.b1, &tb, &hit.mat_id);
         }
+        CFT_STAMP(4);   // (diagnostic build: "park" = the exact evaluation and hit record of the slots; "epilogue" = shading)
         f3 thr = mk3(b.z, b.w, c.x), npos, ndir;
         const bool alive = live && shade_one(S, hit, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), &thr, __float_as_uint(c.y), A.level,
                                              A.max_depth, A.pid_base, A.k0, A.k1, A.radiance, A.pq, A.phong_counts, &npos, &ndir);
@@ -2173,6 +2174,7 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(LevelArgs) {
           PARK(r, 4) = ndir.y; PARK(r, 5) = ndir.z; PARK(r, 6) = thr.x;  PARK(r, 7) = thr.y;
           PARK(r, 8) = thr.z;
         }
+        CFT_STAMP(5);
       }
     }
     CFT_STAMP(5);
