@@ -867,6 +867,38 @@ def test_grid_far_origins_go_to_the_rescan(rt):
     assert np.array_equal(out[0][0], out[1][0])
     assert list(out[0][1].rays_per_level[:depth]) == list(out[1][1].rays_per_level[:depth])
     assert int(out[1][1].exact_rescan) > int(out[0][1].exact_rescan) + 1000   # the far bounce rays@pytest.mark.gpu
+def test_tile_lists_random_cameras(rt):
+    """The per-tile lists against cameras picked to break the binning: inside and outside the cloud of primitives,
+    looking up, down and along the ground, fov from 15 to 140 degrees, pinhole to the widest lens the lists accept,
+    focus planes in front of and behind the scene, frames of one tile and of a few, odd aspect ratios.  Random worlds with
+    moving spheres (binned by their swept bounds), triangles, squares and a cube.  Lists on and off: same bits."""
+    A = rt
+    dev = rt.default_device()
+    rng = np.random.default_rng(77)
+    for case in range(24):
+        world, _ = _random_world(rt, 1 + case % 4)
+        inside = case % 3 != 0
+        pos = tuple(rng.uniform(-7, 7, 2)) + (float(rng.uniform(0.05, 2.5)),) if inside else \
+            tuple(rng.uniform(9, 16, 2) * rng.choice([-1, 1], 2)) + (float(rng.uniform(0.3, 8.0)),)
+        to = tuple(rng.uniform(-6, 6, 2)) + (float(rng.uniform(-1.0, 4.0)),)
+        focus = float(rng.choice([0.8, 3.0, 9.0, 30.0]))
+        aperture = float(rng.choice([0.0, 0.02, 0.1, 0.24])) * focus * 0.5   # (lens radius up to 0.06 of the focus distance)
+        W, H = [(32, 8), (64, 16), (96, 40), (160, 64), (256, 32)][case % 5]
+        cam = (A.Camera.new(pos, to).with_focus_dist(focus).with_aperture(aperture)
+               .with_fov(float(rng.choice([15.0, 45.0, 90.0, 140.0]))).with_aspect(float(rng.choice([W / H, 1.0, 2.5])))
+               .with_sample_rate(3))
+        res = []
+        try:
+            for on in (0, 1):
+                dev.set_tile_lists(on)
+                res.append(world.render(cam, W, H, 4, seed=case, return_stats=True))
+        finally:
+            dev.set_tile_lists(1)
+        assert np.array_equal(res[0][0], res[1][0]), (case, pos, to, focus, aperture, W, H)
+        assert list(res[0][1].rays_per_level[:4]) == list(res[1][1].rays_per_level[:4]), case
+
+
+@pytest.mark.gpu
 def test_tile_lists_are_exact(rt):
     """Primary rays of a tiled frame (width % 32 == 0, height % 8 == 0) scan per-tile primitive lists built per render
     call from the primitives' bounding spheres, the lens and the tile pyramids.  The lists must be supersets of what
