@@ -1300,10 +1300,10 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
                   wk[0], (double)wk[1] / wk[0], (double)wk[2] / wk[0], (double)wk[3] / wk[0], (double)wk[8] / wk[0], (double)wk[9] / wk[0],
                   (double)wk[10] / wk[0], (double)wk[11] / wk[0], (double)wk[12] / wk[0], (double)wk[13] / wk[0], (double)wk[16] / wk[0],
                   (double)wk[17] / wk[0], (double)wk[18] / wk[0], (double)wk[19] / wk[0], (double)wk[20] / wk[0], (double)wk[21] / wk[0], (double)wk[22] / wk[0]);
-        if (l < 4 && wk[24])   // the one-loop walk: per trip (one call of a wave), the passes of each phase and the lanes in them
-          fprintf(stderr, "  walk loop: %.0f calls | per call: rounds %.1f, set-up passes %.1f (%.1f lanes), search steps %.1f (%.1f lanes), candidate passes %.1f (%.1f lanes)\n",
-                  trips, (double)wk[24] / trips, (double)wk[25] / trips, (double)wk[26] / (double)(wk[25] ? wk[25] : 1), (double)wk[27] / trips,
-                  (double)wk[28] / (double)(wk[27] ? wk[27] : 1), (double)wk[29] / trips, (double)wk[30] / (double)(wk[29] ? wk[29] : 1));
+        if (l < 4 && wk[24])   // lanes in each part of the walk's loop, per execution by a wave
+          fprintf(stderr, "  walk loop per ray slot of a wave (%.0f): step %.1f executions with %.1f lanes | batch %.1f with %.1f lanes | candidate path %.1f with %.1f lanes\n",
+                  (double)hc[l] / 64.0, (double)wk[24] / ((double)hc[l] / 64.0), (double)wk[1] / (double)wk[24], (double)wk[25] / ((double)hc[l] / 64.0),
+                  (double)wk[27] / (double)(wk[25] ? wk[25] : 1), (double)wk[26] / ((double)hc[l] / 64.0), (double)wk[3] / (double)(wk[26] ? wk[26] : 1));
       }
     }
 #endif

@@ -664,10 +664,14 @@ __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>&
   uint2 cell = cells[__umul24(__umul24((uint32_t)cz, (uint32_t)S.gny) + (uint32_t)cy, (uint32_t)S.gnx) + (uint32_t)cx];   // < 2^21
 #ifdef CFT_STAMPS
   uint32_t wk_cells = 0, wk_tests = 0, wk_pass = 0;
+  // how many lanes are in each part of the loop when the wave runs it: executions are counted by the first active lane
+  uint32_t wk_xstep = 0, wk_xbatch = 0, wk_xcand = 0, wk_batches = 0;
+#define CFT_WK_LEADER() ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)__ballot(1)) - 1u)
 #endif
   while (true) {
 #ifdef CFT_STAMPS
     wk_cells += 1; wk_tests += (cell.x & 255u) + ((cell.y >> 4) & 255u);
+    wk_xstep += CFT_WK_LEADER() ? 1u : 0u;
 #endif
     const float tnr = fminf(tmx, fminf(tmy, tmz));   // exit of this cell, from p
     {   // step into the neighbour across the nearest plane (straight-line: three-way branches diverge)
@@ -685,6 +689,9 @@ __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>&
     // visited holds 1.3 (S500) to 2.2 (S20k) entries on average: batches of 4 mostly test clamped repeats.
     for (uint32_t e0 = cell.x >> 8, ee = (cell.x >> 8) + (cell.x & 255u); e0 < ee; e0 += (uint32_t)CFT_WALK_BATCH) {
       float4 a4[CFT_WALK_BATCH];
+#ifdef CFT_STAMPS
+      wk_batches += 1; wk_xbatch += CFT_WK_LEADER() ? 1u : 0u;
+#endif
 #pragma unroll
       for (int j = 0; j < CFT_WALK_BATCH; ++j) a4[j] = S.gridSph[min(e0 + (uint32_t)j, ee - 1u)];
       uint32_t pass = 0u;
@@ -704,7 +711,7 @@ __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>&
       }
       while (pass) {
 #ifdef CFT_STAMPS
-        wk_pass += 1;
+        wk_pass += 1; wk_xcand += CFT_WK_LEADER() ? 1u : 0u;
 #endif
         const uint32_t e = e0 + (uint32_t)__builtin_ctz(pass);
         pass &= pass - 1u;
@@ -764,6 +771,8 @@ __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>&
     atomicAdd(&g_walk_stats[8 + bin], 1ull);
     const int tb = wk_tests < 4 ? 0 : wk_tests < 8 ? 1 : wk_tests < 16 ? 2 : wk_tests < 32 ? 3 : wk_tests < 64 ? 4 : wk_tests < 128 ? 5 : 6;
     atomicAdd(&g_walk_stats[16 + tb], 1ull);
+    atomicAdd(&g_walk_stats[24], (unsigned long long)wk_xstep); atomicAdd(&g_walk_stats[25], (unsigned long long)wk_xbatch);
+    atomicAdd(&g_walk_stats[26], (unsigned long long)wk_xcand); atomicAdd(&g_walk_stats[27], (unsigned long long)wk_batches);
   }
 #endif
 }
@@ -2190,6 +2199,7 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(LevelArgs) {
       const uint32_t oseg = A.out_k > 1u ? it % A.out_k : 0u;
       if (lane == leader) wbase = atomicAdd(&A.counts[oseg * CFT_SHARD_STRIDE + A.level + 1], total);
       wbase = __shfl(wbase, (int)leader) + oseg * A.out_D;
+      // (the R path-id loads issued together ahead of an unrolled loop: slower, S500 17.8 -> 18.5 ms)
 #pragma unroll 1
       for (int r = 0; r < R; ++r) {
         const unsigned long long m = __ballot((alive_bits >> r) & 1u);
