@@ -1130,7 +1130,7 @@ static int build_tile_lists(cftrt_scene* s, const CamDev& C, const cftrt_camera*
   if (!ctx->tile_lists || ctx->split || n < 64 || C.width % 32u || C.height % 8u) return CFTRT_OK;
   const uint32_t ntx = C.width / 32u, nty = C.height / 8u, nt = ntx * nty;
   if (ntx > 65535u || nty > 65535u) return CFTRT_OK;
-  {   // lens radius against the distance of the viewport plane (k_tile_bin divides by 1 - a / fd)
+  {   // lens radius against the distance of the viewport plane (the blur a |1 - depth / fd| that k_tile_bin widens a primitive by stays small against it)
     const double lu = std::sqrt(cam->up[0] * cam->up[0] + cam->up[1] * cam->up[1] + cam->up[2] * cam->up[2]);
     const double ls = std::sqrt(cam->sight[0] * cam->sight[0] + cam->sight[1] * cam->sight[1] + cam->sight[2] * cam->sight[2]);
     const double fd = cam->focus_dist * ls;   // (up to the tilt of a non-orthogonal `up`: a factor the 1/8 absorbs)
@@ -1143,7 +1143,7 @@ static int build_tile_lists(cftrt_scene* s, const CamDev& C, const cftrt_camera*
   hipStream_t st = ctx->stream;
   HIP_TRY(ctx, hipMemsetAsync(ctx->tile_cnt.p, 0, (size_t)nt * 4, st));
   const uint32_t g = (uint32_t)std::min<uint64_t>(((uint64_t)n * 64 + CFT_BLOCK - 1) / CFT_BLOCK, (uint64_t)ctx->n_cu * 8);   // a wave per primitive
-  hipLaunchKernelGGL(k_tile_bin, dim3(g), dim3(CFT_BLOCK), 0, st, C, S.boundF, n, S.bcx, S.bcy, S.bcz, ntx, nty,
+  hipLaunchKernelGGL(k_tile_bin, dim3(g), dim3(CFT_BLOCK), 0, st, C, S.boundF, (const float4*)S.triF, (uint32_t)(S.n_sphF + S.n_msph), n, S.bcx, S.bcy, S.bcz, ntx, nty,
                      (TileRange*)ctx->tile_rng.p, (uint32_t*)ctx->tile_cnt.p, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0);
   hipLaunchKernelGGL(k_tile_prefix, dim3(1), dim3(CFT_BLOCK), 0, st, (uint32_t*)ctx->tile_cnt.p, nt, (uint32_t*)ctx->tile_off.p);
   uint32_t total = 0;
@@ -1151,7 +1151,7 @@ static int build_tile_lists(cftrt_scene* s, const CamDev& C, const cftrt_camera*
   HIP_TRY(ctx, hipStreamSynchronize(st));
   if ((uint64_t)total * 4 > (1ull << 30)) return CFTRT_OK;   // (a scene wrapped around the camera: not worth a GiB of lists)
   if ((rc = ensure(ctx, ctx->tile_idx, std::max<size_t>((size_t)total * 4, 256)))) return rc;
-  hipLaunchKernelGGL(k_tile_bin, dim3(g), dim3(CFT_BLOCK), 0, st, C, S.boundF, n, S.bcx, S.bcy, S.bcz, ntx, nty,
+  hipLaunchKernelGGL(k_tile_bin, dim3(g), dim3(CFT_BLOCK), 0, st, C, S.boundF, (const float4*)S.triF, (uint32_t)(S.n_sphF + S.n_msph), n, S.bcx, S.bcy, S.bcz, ntx, nty,
                      (TileRange*)ctx->tile_rng.p, (uint32_t*)ctx->tile_cnt.p, (const uint32_t*)ctx->tile_off.p,
                      (uint32_t*)ctx->tile_idx.p, 1);
   HIP_TRY(ctx, hipGetLastError());

@@ -1301,9 +1301,10 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_generate(CamDev C, uint64_t pid_b
 // |o - pos| <= a, through a viewport point F = tl + fw pw - fh ph (primary_ray above).  With the pinhole ray
 // P(s) = pos + s (F - pos), the real ray is X(s) = P(s) + (1 - s)(o - pos): within a |1 - s| of the pinhole ray at the
 // same s, and s = depth / fd (depth along the viewport normal g, fd = (tl - pos).g; the lens lies in the plane
-// through pos spanned by right and up, so o has depth 0).  X can touch the sphere only where the depth is at most
-// z + rho, so the pinhole ray passes within
-//     rho = (r + a (1 + z / fd)) / (1 - a / fd)        (z = depth of c; solves rho = r + a (1 + (z + rho) / fd))
+// through pos spanned by right and up, so o has depth 0): the blur vanishes in the plane of focus and grows with the
+// distance from it.  X can touch the sphere only at depths within r of z, the depth of c, where |1 - s| is at most
+// (|z - fd| + r) / fd, so the pinhole ray passes within
+//     rho = r + a (|z - fd| + r) / fd
 // of c.  The pinhole rays of tile column tx lie between the planes through pos that contain the viewport lines
 // fw = 32 tx - 0.5 and fw = 32 (tx + 1) - 0.5 (pixel jitter is +-0.5); likewise the rows.  A sphere wholly in front of the
 // camera meets that wedge only if it is not wholly on the far side of either plane: two signed plane distances
@@ -1315,7 +1316,7 @@ struct TileRange { uint16_t tx0, tx1, ty0, ty1; };   // inclusive; tx0 > tx1: no
 // One WAVE per primitive: the lanes share out the column and row boundaries (two plane tests each, no square root:
 // d >= -rho  <=>  N.v >= 0 or (N.v)^2 <= rho^2 |N|^2), ballots give the first and last column / row, then the lanes
 // share out the tiles of the range.  pass 0: ranges and per-tile counts; pass 1 (after the prefix sum): the lists.
-__global__ __launch_bounds__(CFT_BLOCK) void k_tile_bin(CamDev C, const float4* boundF, uint32_t n, float bcx, float bcy,
+__global__ __launch_bounds__(CFT_BLOCK) void k_tile_bin(CamDev C, const float4* boundF, const float4* triF, uint32_t n_sm, uint32_t n, float bcx, float bcy,
                                                         float bcz, uint32_t ntx, uint32_t nty, TileRange* ranges,
                                                         uint32_t* cnt, const uint32_t* off, uint32_t* idx, int pass) {
   const uint32_t lane = threadIdx.x & 63u;
@@ -1342,16 +1343,43 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_tile_bin(CamDev C, const float4* 
       const float4 b = boundF[i];
       const d3 v = d3{(double)b.x + (double)bcx, (double)b.y + (double)bcy, (double)b.z + (double)bcz} - pos;
       const double z = ddot(v, g), lv = sqrt(ddot(v, v));
-      double rho = ((double)b.w + a * (1. + fmax(z, 0.) / fd)) / (1. - a / fd);   // (the host only bins when a < fd / 8)
-      rho = rho * 1.0001 + 1e-5 * (1. + lv + lpos);
+      // A sphere is one point widened by rho; a TRIANGLE is its three corners widened by the blur alone: a ray that
+      // touches it does so at a point X of it, the pinhole ray passes within a |z_X - fd| / fd of X, and that is
+      // convex in X, so at most the largest of the corners' values - the pinhole ray meets the convex hull of three
+      // balls of that radius, which lies beyond a plane when all three do.  (The bounding sphere of a triangle covers
+      // three to four times the tiles the triangle does.)
+      d3 vv[3] = {v, v, v};
+      double zlo = z, zhi = z, lvv = lv;
+      double rho = (double)b.w + a * (fabs(z - fd) + (double)b.w) / fd;   // (the host only bins when a < fd / 8)
+      const int nv = i >= n_sm ? 3 : 1;
+      if (nv == 3) {
+        const float4 p0 = triF[3 * (size_t)(i - n_sm)], e1 = triF[3 * (size_t)(i - n_sm) + 1], e2 = triF[3 * (size_t)(i - n_sm) + 2];
+        const d3 q0 = d3{(double)p0.x + (double)bcx, (double)p0.y + (double)bcy, (double)p0.z + (double)bcz} - pos;
+        vv[0] = q0;
+        vv[1] = q0 + d3{(double)e1.x, (double)e1.y, (double)e1.z};
+        vv[2] = q0 + d3{(double)e2.x, (double)e2.y, (double)e2.z};
+        rho = 0.; zlo = 1e300; zhi = -1e300; lvv = 0.;
+        for (int j = 0; j < 3; ++j) {
+          const double zj = ddot(vv[j], g);
+          zlo = fmin(zlo, zj); zhi = fmax(zhi, zj);
+          rho = fmax(rho, a * fabs(zj - fd) / fd);
+          lvv = fmax(lvv, sqrt(ddot(vv[j], vv[j])));
+        }
+      }
+      rho = rho * 1.0001 + 1e-5 * (1. + lvv + lpos);
       const double rho2 = rho * rho;
-      if (z + rho <= 0.) {
+      if (zhi + rho <= 0.) {
         // wholly behind the lens plane: no tile
-      } else if (z - rho <= 1e-6 * fd) {
+      } else if (zlo - rho <= 1e-6 * fd) {
         t = TileRange{0, (uint16_t)(ntx - 1), 0, (uint16_t)(nty - 1)};
       } else {
-        // not_below(N): c is not farther than rho on the negative side of the plane with normal N through pos
-        auto not_below = [&](d3 N) { const double d = ddot(N, v); return d >= 0. || d * d <= rho2 * ddot(N, N); };
+        // not_below(N): some corner is not farther than rho on the negative side of the plane with normal N through pos
+        auto not_below = [&](d3 N) {
+          const double nn = rho2 * ddot(N, N);
+          bool ok = false;
+          for (int j = 0; j < nv; ++j) { const double d = ddot(N, vv[j]); ok = ok || d >= 0. || d * d <= nn; }
+          return ok;
+        };
         uint32_t x0 = 0xFFFFFFFFu, x1 = 0u, y0 = 0xFFFFFFFFu, y1 = 0u;
         bool anyx = false, anyy = false;
         for (uint32_t k0 = 0; k0 < ntx; k0 += 64u) {
