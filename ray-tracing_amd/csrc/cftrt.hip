@@ -972,8 +972,10 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
   // (with per-tile lists the primary rays of long-list scenes take them instead of the walk)
   const bool tiles = gen && gen->tiled && S.tile_off && (R == 1 || R == 2 || R == 4);
   const bool walk = S.grid_mode && (level > 0 || (S.grid_mode == 2 && !tiles));
-  if (walk) { if (lean) { CFT_LAUNCH_R(4) } else { CFT_LAUNCH_R(7) } }
-  else      { if (lean) { CFT_LAUNCH_R(0) } else { CFT_LAUNCH_R(3) } }
+  // (no moving spheres, but triangles - cornell, S20k: without the moving-sphere code the pack spills half as much)
+  const bool no_msph = !S.n_msph && !two_scans;
+  if (walk) { if (lean) { CFT_LAUNCH_R(4) } else if (no_msph) { CFT_LAUNCH_R(6) } else { CFT_LAUNCH_R(7) } }
+  else      { if (lean) { CFT_LAUNCH_R(0) } else if (no_msph) { CFT_LAUNCH_R(2) } else { CFT_LAUNCH_R(3) } }
 #undef CFT_LAUNCH_R
 #undef CFT_LAUNCH
 }
