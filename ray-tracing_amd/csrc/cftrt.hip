@@ -396,6 +396,43 @@ int cftrt_scene_set_precise_radius(cftrt_scene* s, double radius) {
   return CFTRT_OK;
 }
 
+// Does the triangle v[0..8] (three corners) meet the box (centre c, half-extents h)?  Separating axes: the box's three
+// (done by the caller's cell ranges, repeated here), the triangle's normal, and the nine edge x axis products
+// (Akenine-Moller).  Conservative: "separated" needs a gap above 1e-9 of the sizes involved.
+static bool tri_box_overlap(const double c[3], const double h[3], const double* v) {
+  double p[3][3];
+  for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) p[j][k] = v[3 * j + k] - c[k];
+  double scale = h[0] + h[1] + h[2];
+  for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) scale = std::max(scale, std::fabs(p[j][k]));
+  const double tol = 1e-9 * scale;
+  for (int k = 0; k < 3; ++k) {
+    const double lo = std::min(p[0][k], std::min(p[1][k], p[2][k])), hi = std::max(p[0][k], std::max(p[1][k], p[2][k]));
+    if (lo > h[k] + tol || hi < -h[k] - tol) return false;
+  }
+  const double e[3][3] = {{p[1][0] - p[0][0], p[1][1] - p[0][1], p[1][2] - p[0][2]},
+                          {p[2][0] - p[1][0], p[2][1] - p[1][1], p[2][2] - p[1][2]},
+                          {p[0][0] - p[2][0], p[0][1] - p[2][1], p[0][2] - p[2][2]}};
+  auto separated = [&](const double a[3]) {
+    const double al = std::fabs(a[0]) + std::fabs(a[1]) + std::fabs(a[2]);
+    if (al == 0.) return false;
+    double lo = 1e300, hi = -1e300;
+    for (int j = 0; j < 3; ++j) { const double d = a[0] * p[j][0] + a[1] * p[j][1] + a[2] * p[j][2]; lo = std::min(lo, d); hi = std::max(hi, d); }
+    const double r = h[0] * std::fabs(a[0]) + h[1] * std::fabs(a[1]) + h[2] * std::fabs(a[2]);
+    const double t = tol * al;
+    return lo > r + t || hi < -r - t;
+  };
+  const double nrm[3] = {e[0][1] * e[1][2] - e[0][2] * e[1][1], e[0][2] * e[1][0] - e[0][0] * e[1][2], e[0][0] * e[1][1] - e[0][1] * e[1][0]};
+  if (separated(nrm)) return false;
+  for (int j = 0; j < 3; ++j)
+    for (int k = 0; k < 3; ++k) {
+      double a[3] = {0., 0., 0.};   // unit axis k x edge j
+      const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+      a[k1] = -e[j][k2]; a[k2] = e[j][k1];
+      if (separated(a)) return false;
+    }
+  return true;
+}
+
 int cftrt_scene_commit(cftrt_scene* s) {
   if (!s) return CFTRT_ERR_INVALID;
   if (s->committed) return fail(s->ctx, CFTRT_ERR_STATE, "scene already committed");
@@ -567,10 +604,12 @@ int cftrt_scene_commit(cftrt_scene* s) {
       for (int k = 0; k < 3; ++k) { cen[3 * i + k] = c[k]; bx[i].lo[k] = c[k] - r; bx[i].hi[k] = c[k] + r; }
       rad[i] = r;
     }
+    std::vector<double> triV(9 * (size_t)nT);   // corners of the static triangles as the kernels' f32 data give them
     for (int i = 0; i < nT; ++i) {
       const float4 p0 = triF[3 * i], e1 = triF[3 * i + 1], e2 = triF[3 * i + 2];
       const double v[3][3] = {{p0.x, p0.y, p0.z}, {(double)p0.x + e1.x, (double)p0.y + e1.y, (double)p0.z + e1.z},
                               {(double)p0.x + e2.x, (double)p0.y + e2.y, (double)p0.z + e2.z}};
+      for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) triV[9 * (size_t)i + 3 * j + k] = v[j][k];
       Box& b = bx[nS + nM + i];
       for (int k = 0; k < 3; ++k) {
         b.lo[k] = std::min(v[0][k], std::min(v[1][k], v[2][k]));
@@ -638,6 +677,11 @@ int cftrt_scene_commit(cftrt_scene* s) {
                   }
                   const double rr = rad[i] + margin;
                   if (d2 > rr * rr) continue;
+                } else {   // triangle against the cell box (widened by the margin), not just its own box against it
+                  const int c3[3] = {x, y, z};
+                  double bc3[3], bh[3];
+                  for (int k = 0; k < 3; ++k) { bc3[k] = blo[k] + (c3[k] + 0.5) * cs[k]; bh[k] = 0.5 * cs[k] + margin; }
+                  if (!tri_box_overlap(bc3, bh, &triV[9 * (size_t)(i - nS - nM)])) continue;
                 }
                 f(((size_t)z * n[1] + y) * n[0] + x);
               }
