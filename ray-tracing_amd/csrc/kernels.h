@@ -2227,6 +2227,23 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(LevelArgs) {
       const uint32_t oseg = A.out_k > 1u ? it % A.out_k : 0u;
       if (lane == leader) wbase = atomicAdd(&A.counts[oseg * CFT_SHARD_STRIDE + A.level + 1], total);
       wbase = __shfl(wbase, (int)leader) + oseg * A.out_D;
+      // The survivor's path id is re-read from the input queue (a dependent load per slot) - except at level 0, where
+      // the launch generated the rays itself and the id follows from the slot (generate_slot's numbering).
+      bool lp_known = false;
+      uint32_t lp0 = 0u, lp_slot0 = 0u, lp_w = 0u;   // tiled: path id and slot of the tile's first pixel, image width
+      if constexpr (GEN && !SORT) {
+        if (!A.gen.tiled) {
+          lp_known = true;
+        } else if (256 % (64 * R) == 0) {
+          const uint32_t npix = A.gen.cam.width * A.gen.cam.height, ntx = A.gen.cam.width >> 5;
+          const uint32_t wbu = (uint32_t)__builtin_amdgcn_readfirstlane((int)wb);
+          const uint32_t smp = wbu / npix, t = (wbu - smp * npix) >> 8, ty = t / ntx, tx = t - ty * ntx;
+          lp_w = A.gen.cam.width;
+          lp0 = smp * npix + ty * 8u * lp_w + tx * 32u;
+          lp_slot0 = smp * npix + (t << 8);
+          lp_known = true;
+        }
+      }
       // (the R path-id loads issued together ahead of an unrolled loop: slower, S500 17.8 -> 18.5 ms)
 #pragma unroll 1
       for (int r = 0; r < R; ++r) {
@@ -2235,7 +2252,14 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(LevelArgs) {
           const uint32_t o = wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
           qout.a[o] = make_float4(PARK(r, 0), PARK(r, 1), PARK(r, 2), PARK(r, 3));
           qout.b[o] = make_float4(PARK(r, 4), PARK(r, 5), PARK(r, 6), PARK(r, 7));
-          qout.c[o] = make_float2(PARK(r, 8), q.c[slot_index(r, base)].y);
+          float pidw;
+          if (lp_known) {
+            const uint32_t i = base + (uint32_t)r * 64u, wi = i - lp_slot0;
+            pidw = __uint_as_float(lp_w ? lp0 + (wi >> 5) * lp_w + (wi & 31u) : i);
+          } else {
+            pidw = q.c[slot_index(r, base)].y;
+          }
+          qout.c[o] = make_float2(PARK(r, 8), pidw);
         }
         wbase += (uint32_t)__popcll(m);
       }
