@@ -20,7 +20,12 @@ def with_squares(zlo, zhi, n=500, seed=12345):
         w.add_obj(A.Object(A.Square(center, x, y, 0.5), d.with_color((0.5, 0.5, 0.5))))
     return w, c
 
-for name, (w, c) in (("no squares", rt.scenes.s20k(n_squares=0)), ("squares z 0.3..1.0", with_squares(0.3, 1.0)),
+def one_tiny_square():
+    w, c = rt.scenes.s20k(n_squares=0)
+    w.add_obj(A.Object(A.Square((0.013, 0.017, 0.2), (1.0, 0.0, 0.0), (0.0, 1.0, 0.0), 1e-3), A.LambertianModel(1.0).with_color((0.5, 0.5, 0.5))))
+    return w, c
+
+for name, (w, c) in (("no squares", rt.scenes.s20k(n_squares=0)), ("no squares + one 1e-3 square (the kernels with triangle code)", one_tiny_square()), ("squares z 0.3..1.0", with_squares(0.3, 1.0)),
                      ("squares z 0.1..0.3", with_squares(0.1, 0.3))):
     c = c.with_sample_rate(64)
     for depth in (1, 50):
