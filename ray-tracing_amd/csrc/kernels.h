@@ -1263,7 +1263,8 @@ struct TileHint { uint32_t smp, tx, ty, slot0; };   // slot0 = the queue slot of
 #define CFT_NO_TILE_HINT TileHint{0u, 0u, 0u, 0xFFFFFFFFu}
 __device__ __forceinline__ void generate_slot(const CamDev& C, uint64_t pid_base, uint32_t i, uint32_t k0, uint32_t k1,
                                               int jitter, int tiled, const QueueDev& q, float4* a_out = nullptr,
-                                              float4* b_out = nullptr, uint32_t* lp_out = nullptr, TileHint th = CFT_NO_TILE_HINT) {
+                                              float4* b_out = nullptr, uint32_t* lp_out = nullptr, TileHint th = CFT_NO_TILE_HINT,
+                                              bool lean = false) {
   uint32_t lp = i, pix = 0xFFFFFFFFu, pxw = 0xFFFFFFFFu, pxh = 0u;
   if (tiled && th.slot0 != 0xFFFFFFFFu) {
     const uint32_t wi = i - th.slot0;   // 0 .. 255 inside the tile
@@ -1283,8 +1284,14 @@ __device__ __forceinline__ void generate_slot(const CamDev& C, uint64_t pid_base
   primary_ray(C, pid_base + lp, k0, k1, jitter, &pos, &dir, pix, pxw, pxh);
   const float4 a = make_float4(pos.x, pos.y, pos.z, dir.x), b = make_float4(dir.y, dir.z, 1.0f, 1.0f);
   q.a[i] = a;
-  q.b[i] = b;
-  q.c[i] = make_float2(1.0f, __uint_as_float(lp));
+  if (lean) {
+    // (the fused level-0 launch, which reads the ray back itself: throughput 1 and the path id follow from the level
+    // and the slot, so 24 of the 40 bytes are written and read back - that launch runs at the HBM's speed)
+    *(float2*)&q.b[i] = make_float2(b.x, b.y);
+  } else {
+    q.b[i] = b;
+    q.c[i] = make_float2(1.0f, __uint_as_float(lp));
+  }
   if (a_out) { *a_out = a; *b_out = b; *lp_out = lp; }
 }
 
@@ -1497,7 +1504,7 @@ __device__ __forceinline__ void isect_setup(const SceneDev& S, const QueueDev& q
                                             uint32_t stride, uint32_t level, uint64_t pid_base, uint32_t k0,
                                             uint32_t k1, uint32_t role0, uint32_t role1, RayPack<R, NS>& P,
                                             float (*park)[CFT_BLOCK], const uint16_t (*perm)[CFT_BLOCK] = nullptr,
-                                            const GenArgs* gen = nullptr, TileHint th = CFT_NO_TILE_HINT) {
+                                            const GenArgs* gen = nullptr, TileHint th = CFT_NO_TILE_HINT, bool lean = false) {
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     // (with perm, base is the wave's first ray)
@@ -1513,7 +1520,7 @@ __device__ __forceinline__ void isect_setup(const SceneDev& S, const QueueDev& q
     if (i < n) {
       float4 a, b;
       uint32_t lp = 0;
-      if (gen) generate_slot(gen->cam, pid_base, i, k0, k1, gen->jitter, gen->tiled, q, &a, &b, &lp, th);
+      if (gen) generate_slot(gen->cam, pid_base, i, k0, k1, gen->jitter, gen->tiled, q, &a, &b, &lp, th, lean);
       else { a = q.a[i]; b = q.b[i]; }
       ox = a.x; oy = a.y; oz = a.z; dx = a.w; dy = b.x; dz = b.y;
       if (S.any_motion) {
@@ -2111,6 +2118,14 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(LevelArgs) {
     const uint32_t wb = (it - seg_trip0) * 64u * R;
     const uint32_t base = wb + lane;
     QueueDev q;   // the trip's segment of the input queue, indexed from 0
+    // Level 0 of the fused pipeline (the launch generated the rays itself): the path id of a slot follows from the slot
+    // (generate_slot's numbering) - lp_known; then only 24 bytes of a ray went to the queue and come back.
+    bool lp_known = false;
+    uint32_t lp0 = 0u, lp_slot0 = 0u, lp_w = 0u;   // tiled: path id and slot of the tile's first pixel, image width (0: lp = slot)
+    auto slot_lp = [&](uint32_t i) -> uint32_t {
+      const uint32_t wi = i - lp_slot0;
+      return lp_w ? lp0 + (wi >> 5) * lp_w + (wi & 31u) : i;
+    };
     {
       // ---- the rays of the trip: (generated,) sorted, set up, scanned, parked
       const LevelArgs& A = level_args();
@@ -2152,8 +2167,14 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(LevelArgs) {
           th.ty = t / ntx;
           th.tx = t - th.ty * ntx;
           th.slot0 = th.smp * npix + (t << 8);
+          lp_w = A.gen.cam.width;
+          lp0 = th.smp * npix + th.ty * 8u * lp_w + th.tx * 32u;
+          lp_slot0 = th.slot0;
+          lp_known = true;
+        } else if (!A.gen.tiled) {
+          lp_known = true;   // (lp = slot)
         }
-        isect_setup<R, NS>(S, q, n, base, stride, A.level, A.pid_base, A.k0, A.k1, A.role0, A.role1, P, park, nullptr, &A.gen, th);
+        isect_setup<R, NS>(S, q, n, base, stride, A.level, A.pid_base, A.k0, A.k1, A.role0, A.role1, P, park, nullptr, &A.gen, th, lp_known);
       } else {
         isect_setup<R, NS>(S, q, n, base, stride, A.level, A.pid_base, A.k0, A.k1, A.role0, A.role1, P, park);
       }
@@ -2180,8 +2201,13 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(LevelArgs) {
       // the slot's ray is re-read from the queue (HBM: the queue is far bigger than the caches); the next slot's
       // loads are issued before this slot is processed
       uint32_t inext = slot_index(0, base);
-      float4 an = q.a[inext < n ? inext : wb], bn = q.b[inext < n ? inext : wb];
-      float2 cn = q.c[inext < n ? inext : wb];
+      auto load_b = [&](uint32_t j) -> float4 {
+        if (lp_known) { const float2 t = *(const float2*)&q.b[j]; return make_float4(t.x, t.y, 1.0f, 1.0f); }
+        return q.b[j];
+      };
+      auto load_c = [&](uint32_t j) -> float2 { return lp_known ? make_float2(1.0f, __uint_as_float(slot_lp(j))) : q.c[j]; };
+      float4 an = q.a[inext < n ? inext : wb], bn = load_b(inext < n ? inext : wb);
+      float2 cn = load_c(inext < n ? inext : wb);
 #pragma unroll 1
       for (int r = 0; r < R; ++r) {
         if (!(wb + r * stride < n)) break;   // wave-uniform: the whole wave stays together for isect_hit
@@ -2192,7 +2218,7 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(LevelArgs) {
         {
           inext = r + 1 < R ? slot_index(r + 1, base) : 0xFFFFFFFFu;
           const uint32_t j = inext < n ? inext : wb;
-          an = q.a[j]; bn = q.b[j]; cn = q.c[j];
+          an = q.a[j]; bn = load_b(j); cn = load_c(j);
         }
         HitInRegisters hit;
         isect_hit<NS>(S, live, r, 0, a.x, a.y, a.z, a.w, b.x, b.y, park, A.stats, &hit.a0, &hit.b1, &hit.ta, &hit.mat_id);
@@ -2227,23 +2253,7 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(LevelArgs) {
       const uint32_t oseg = A.out_k > 1u ? it % A.out_k : 0u;
       if (lane == leader) wbase = atomicAdd(&A.counts[oseg * CFT_SHARD_STRIDE + A.level + 1], total);
       wbase = __shfl(wbase, (int)leader) + oseg * A.out_D;
-      // The survivor's path id is re-read from the input queue (a dependent load per slot) - except at level 0, where
-      // the launch generated the rays itself and the id follows from the slot (generate_slot's numbering).
-      bool lp_known = false;
-      uint32_t lp0 = 0u, lp_slot0 = 0u, lp_w = 0u;   // tiled: path id and slot of the tile's first pixel, image width
-      if constexpr (GEN && !SORT) {
-        if (!A.gen.tiled) {
-          lp_known = true;
-        } else if (256 % (64 * R) == 0) {
-          const uint32_t npix = A.gen.cam.width * A.gen.cam.height, ntx = A.gen.cam.width >> 5;
-          const uint32_t wbu = (uint32_t)__builtin_amdgcn_readfirstlane((int)wb);
-          const uint32_t smp = wbu / npix, t = (wbu - smp * npix) >> 8, ty = t / ntx, tx = t - ty * ntx;
-          lp_w = A.gen.cam.width;
-          lp0 = smp * npix + ty * 8u * lp_w + tx * 32u;
-          lp_slot0 = smp * npix + (t << 8);
-          lp_known = true;
-        }
-      }
+      // The survivor's path id is re-read from the input queue (a dependent load per slot) - except at level 0 (lp_known)
       // (the R path-id loads issued together ahead of an unrolled loop: slower, S500 17.8 -> 18.5 ms)
 #pragma unroll 1
       for (int r = 0; r < R; ++r) {
@@ -2254,8 +2264,7 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(LevelArgs) {
           qout.b[o] = make_float4(PARK(r, 4), PARK(r, 5), PARK(r, 6), PARK(r, 7));
           float pidw;
           if (lp_known) {
-            const uint32_t i = base + (uint32_t)r * 64u, wi = i - lp_slot0;
-            pidw = __uint_as_float(lp_w ? lp0 + (wi >> 5) * lp_w + (wi & 31u) : i);
+            pidw = __uint_as_float(slot_lp(base + (uint32_t)r * 64u));
           } else {
             pidw = q.c[slot_index(r, base)].y;
           }
