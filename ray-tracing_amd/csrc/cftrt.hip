@@ -951,7 +951,7 @@ static void launch_intersect(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, cons
 // gen != null (level 0): the launch generates the primary rays itself (no k_generate).
 static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, uint32_t* counts, uint32_t level,
                                uint32_t max_depth, uint64_t pid_base, uint32_t k0, uint32_t k1, bool two_scans,
-                               uint32_t role0, uint32_t role1, QueueDev qout, float4* rad, PhongQueueDev pq,
+                               uint32_t role0, uint32_t role1, QueueDev qout, Rad3* rad, PhongQueueDev pq,
                                uint32_t* phong_counts, uint32_t* xstats, uint32_t P, const GenArgs* gen, uint32_t in_D,
                                uint32_t* out_D_io) {
   // *out_D_io on entry: nonzero = the caller wants the output queue sharded; on return: the segment stride used (0: dense)
@@ -1079,7 +1079,7 @@ struct PassBufs {
   QueueDev q[2];
   HitDev hA, hB;
   PhongQueueDev pq;
-  float4* rad;
+  Rad3* rad;
   uint32_t* counts;
 };
 static const size_t kShardWords = 2 * CFTRT_MAX_LEVELS + 8 + 128 + 2 + 4 * 64;   // (+ walk counters of the diagnostic build)   // used words of shard 0's block
@@ -1091,7 +1091,7 @@ static_assert(CFTRT_MAX_LEVELS == CFTRT_MAX_LEVELS_DEV, "kernels.h and cftrt.h d
 
 static uint64_t bytes_per_path(const cftrt_ctx* ctx, const SceneDev& S) {
   const bool two_scans = S.any_motion && S.n_lights > 0;
-  return 80 + 16 + (ctx->split ? (two_scans ? 80 : 40) : 0) + (S.n_phong_mats ? 56 : 0);
+  return 80 + 12 + (ctx->split ? (two_scans ? 80 : 40) : 0) + (S.n_phong_mats ? 56 : 0);
 }
 
 // From the ctx's grow-only hipMalloc'ed workspace.
@@ -1110,7 +1110,7 @@ static int bufs_from_ctx(cftrt_ctx* ctx, const SceneDev& S, uint32_t P, PassBufs
     if ((rc = ensure(ctx, ctx->h1[k], (size_t)P * 16))) return rc;
     if ((rc = ensure(ctx, ctx->ht[k], (size_t)P * 8))) return rc;
   }
-  if ((rc = ensure(ctx, ctx->rad, (size_t)P * 16))) return rc;
+  if ((rc = ensure(ctx, ctx->rad, (size_t)P * 12))) return rc;
   if (phong) {
     if ((rc = ensure(ctx, ctx->pqa, (size_t)P * 16))) return rc;
     if ((rc = ensure(ctx, ctx->pqb, (size_t)P * 16))) return rc;
@@ -1122,7 +1122,7 @@ static int bufs_from_ctx(cftrt_ctx* ctx, const SceneDev& S, uint32_t P, PassBufs
   B->hA = HitDev{(float4*)ctx->h0[0].p, (float4*)ctx->h1[0].p, (double*)ctx->ht[0].p};
   B->hB = two_scans ? HitDev{(float4*)ctx->h0[1].p, (float4*)ctx->h1[1].p, (double*)ctx->ht[1].p} : B->hA;
   B->pq = PhongQueueDev{(float4*)ctx->pqa.p, (float4*)ctx->pqb.p, (float4*)ctx->pqc.p, (uint2*)ctx->pqd.p};
-  B->rad = (float4*)ctx->rad.p;
+  B->rad = (Rad3*)ctx->rad.p;
   B->counts = (uint32_t*)ctx->counts.p;
   return CFTRT_OK;
 }
@@ -1150,7 +1150,7 @@ static int bufs_from_static(cftrt_ctx* ctx, const SceneDev& S, uint32_t P, PassB
     B->q[k].b = (float4*)carve(Q * 16);
     B->q[k].c = (float2*)carve(Q * 8);
   }
-  B->rad = (float4*)carve((size_t)P * 16);
+  B->rad = (Rad3*)carve((size_t)P * 12);
   B->hA = B->hB = HitDev{nullptr, nullptr, nullptr};
   if (ctx->split) {
     B->hA = HitDev{(float4*)carve((size_t)P * 16), (float4*)carve((size_t)P * 16), (double*)carve((size_t)P * 8)};
@@ -1235,7 +1235,7 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
   QueueDev q[2] = {B.q[0], B.q[1]};
   HitDev hA = B.hA, hB = B.hB;
   PhongQueueDev pq = B.pq;
-  float4* rad = B.rad;
+  Rad3* rad = B.rad;
 
   const int tiled = (C.width % 32u == 0 && C.height % 8u == 0 && npix == C.width * C.height && P % npix == 0 && pid_base % npix == 0) ? 1 : 0;
   const GenArgs gen{C, jitter, tiled};
@@ -1587,8 +1587,8 @@ int cftrt_trace_paths(cftrt_scene* s, const cftrt_camera* cam, uint32_t width, u
   }
   int rc = run_pass(s, C, pid0, (uint32_t)n, 1, (uint32_t)n, max_depth, seed, jitter, nullptr, &st, tm);
   if (rc) return rc;
-  std::vector<float4> rad(n);
-  HIP_TRY(ctx, hipMemcpy(rad.data(), ctx->rad.p, n * 16, hipMemcpyDeviceToHost));
+  std::vector<Rad3> rad(n);
+  HIP_TRY(ctx, hipMemcpy(rad.data(), ctx->rad.p, n * 12, hipMemcpyDeviceToHost));
   for (uint64_t i = 0; i < n; ++i) {
     out_rgb[3 * i] = rad[i].x; out_rgb[3 * i + 1] = rad[i].y; out_rgb[3 * i + 2] = rad[i].z;
   }

@@ -332,6 +332,10 @@ __device__ __forceinline__ float tri_lower_bound(const SceneDev& S, float ox, fl
   return r;
 }
 
+// A path's radiance as it waits for k_resolve: 12 bytes (the resolve pass runs at the HBM's speed, a fourth float of
+// padding was a quarter of its traffic).
+struct Rad3 { float x, y, z; };
+
 struct Closest {
   double t;   // exact (f64) distance, +inf on miss
   int g;      // global prim id, -1 on miss
@@ -1790,7 +1794,7 @@ struct PhongQueueDev {   // Phong hits handed to k_shadow: 64 B per entry
 template <typename H>
 __device__ __forceinline__ bool shade_one(const SceneDev& S, const H& hit, f3 pos, f3 dir, f3* thr_io, uint32_t lpid,
                                           uint32_t level, uint32_t max_depth, uint64_t pid_base, uint32_t k0,
-                                          uint32_t k1, float4* radiance, const PhongQueueDev& pq,
+                                          uint32_t k1, Rad3* radiance, const PhongQueueDev& pq,
                                           uint32_t* phong_counts, f3* npos_out, f3* ndir_out) {
   f3 thr = *thr_io;
   f3 npos = mk3(0, 0, 0), ndir = mk3(0, 0, 0);
@@ -1825,10 +1829,10 @@ __device__ __forceinline__ bool shade_one(const SceneDev& S, const H& hit, f3 po
     }
   }
   if (see) {
-    radiance[lpid] = make_float4(thr.x * col.x, thr.y * col.y, thr.z * col.z, 0.f);
+    radiance[lpid] = Rad3{thr.x * col.x, thr.y * col.y, thr.z * col.z};
   } else {
     if (prim < 0) {
-      radiance[lpid] = make_float4(0.f, 0.f, 0.f, 0.f);   // object.rs:354
+      radiance[lpid] = Rad3{0.f, 0.f, 0.f};   // object.rs:354
     } else {
       const float4 B1 = hit.B1();
       HitInfoF h = hitinfo_new(mk3(B1.y, B1.z, B1.w), mk3(B0.z, B0.w, B1.x), dir);
@@ -1877,7 +1881,7 @@ __device__ __forceinline__ bool shade_one(const SceneDev& S, const H& hit, f3 po
       if (scattered) {
         thr = thr * k;
         if (level + 1 < max_depth) alive = true;
-        else radiance[lpid] = make_float4(0.f, 0.f, 0.f, 0.f);   // trace(.., 0) is black (object.rs:327-329)
+        else radiance[lpid] = Rad3{0.f, 0.f, 0.f};   // trace(.., 0) is black (object.rs:327-329)
       }
     }
   }
@@ -1910,7 +1914,7 @@ struct HitInRegisters {   // the fused pipeline
 __global__ __launch_bounds__(CFT_BLOCK) void k_shade(SceneDev S, QueueDev qin, HitDev hitA, HitDev hitB,
                                                      uint32_t* counts, uint32_t level, uint32_t max_depth,
                                                      uint64_t pid_base, uint32_t k0, uint32_t k1, QueueDev qout,
-                                                     float4* radiance, PhongQueueDev pq, uint32_t* phong_counts) {
+                                                     Rad3* radiance, PhongQueueDev pq, uint32_t* phong_counts) {
   // Survivors of a 1024-ray chunk are staged in LDS and appended to the next queue with ONE global
   // atomic per chunk (a returning atomic on one word saturates near 88/us chip-wide, which a
   // per-wave atomic would hit at ~2M waves per level), then copied out coalesced.
@@ -2062,7 +2066,7 @@ struct LevelArgs {
   uint64_t pid_base;
   uint32_t k0, k1, role0, role1;
   QueueDev qout;
-  float4* radiance;
+  Rad3* radiance;
   PhongQueueDev pq;
   uint32_t* phong_counts;
   uint32_t* stats;
@@ -2292,7 +2296,7 @@ template <int R, int NS, int LISTS>
 __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_tail(SceneDev S, QueueDev q, uint32_t* counts, uint32_t level,
                                                           uint32_t max_depth, uint64_t pid_base, uint32_t k0,
                                                           uint32_t k1, uint32_t role0, uint32_t role1, QueueDev qout,
-                                                          float4* radiance, PhongQueueDev pq, uint32_t* phong_counts,
+                                                          Rad3* radiance, PhongQueueDev pq, uint32_t* phong_counts,
                                                           uint32_t* stats) {
   __shared__ float park[ParkLayout<NS>::WORDS * R][CFT_BLOCK];
   const uint32_t n = counts[level];
@@ -2407,7 +2411,7 @@ struct FinishArgs {   // (one struct, read per phase through the kernarg pointer
   uint64_t pid_base;
   uint32_t k0, k1, role0, role1;
   int two_scans;
-  float4* radiance;
+  Rad3* radiance;
   uint32_t* cursor;
   uint32_t* stats;
   uint32_t in_D;
@@ -2521,7 +2525,7 @@ struct ShadowArgs {   // (one struct, read per phase through the kernarg pointer
   uint32_t level;
   uint64_t pid_base;
   uint32_t k0, k1;
-  float4* radiance;
+  Rad3* radiance;
   uint32_t* stats;
 };
 __global__ __launch_bounds__(CFT_BLOCK) void k_shadow(ShadowArgs) {
@@ -2590,7 +2594,7 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_shadow(ShadowArgs) {
       sum = madd3(sum, lcol, inten * w);
     }
     f3 outc = mk3(m.p1 * sum.x * m.r, m.p1 * sum.y * m.g, m.p1 * sum.z * m.b);   // kd * c * color
-    kernel_args<ShadowArgs>().radiance[dd.x] = make_float4(thr.x * outc.x, thr.y * outc.y, thr.z * outc.z, 0.f);
+    kernel_args<ShadowArgs>().radiance[dd.x] = Rad3{thr.x * outc.x, thr.y * outc.y, thr.z * outc.z};
   }
 }
 
@@ -2598,12 +2602,12 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_shadow(ShadowArgs) {
 // one lane = one pixel: the pass's samples are added to accum[pix] one by one, in sample order.  The running sum
 // starts from the value already there, so the result does not depend on how a call's sample range was cut into
 // passes (workspace limit, static workspace): one pass and many give the same bits.
-__global__ __launch_bounds__(CFT_BLOCK) void k_resolve(const float4* radiance, uint32_t npix, uint32_t nsamples,
+__global__ __launch_bounds__(CFT_BLOCK) void k_resolve(const Rad3* radiance, uint32_t npix, uint32_t nsamples,
                                                        float* accum) {
   for (uint32_t p = blockIdx.x * CFT_BLOCK + threadIdx.x; p < npix; p += gridDim.x * CFT_BLOCK) {
     float r = accum[3 * (size_t)p], g = accum[3 * (size_t)p + 1], b = accum[3 * (size_t)p + 2];
     for (uint32_t s = 0; s < nsamples; ++s) {
-      float4 v = radiance[(size_t)s * npix + p];
+      const Rad3 v = radiance[(size_t)s * npix + p];
       r += v.x; g += v.y; b += v.z;
     }
     accum[3 * (size_t)p] = r;
