@@ -1291,7 +1291,8 @@ __device__ __forceinline__ void generate_slot(const CamDev& C, uint64_t pid_base
   if (lean) {
     // (the fused level-0 launch, which reads the ray back itself: throughput 1 and the path id follow from the level
     // and the slot, so 24 of the 40 bytes are written and read back - that launch runs at the HBM's speed)
-    *(float2*)&q.b[i] = make_float2(b.x, b.y);
+    // (dy, dz go into the float2 stream: dense 8-byte stores, where half-filled 16-byte slots would cost whole sectors)
+    q.c[i] = make_float2(b.x, b.y);
   } else {
     q.b[i] = b;
     q.c[i] = make_float2(1.0f, __uint_as_float(lp));
@@ -2206,7 +2207,7 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(LevelArgs) {
       // loads are issued before this slot is processed
       uint32_t inext = slot_index(0, base);
       auto load_b = [&](uint32_t j) -> float4 {
-        if (lp_known) { const float2 t = *(const float2*)&q.b[j]; return make_float4(t.x, t.y, 1.0f, 1.0f); }
+        if (lp_known) { const float2 t = q.c[j]; return make_float4(t.x, t.y, 1.0f, 1.0f); }
         return q.b[j];
       };
       auto load_c = [&](uint32_t j) -> float2 { return lp_known ? make_float2(1.0f, __uint_as_float(slot_lp(j))) : q.c[j]; };
