@@ -835,6 +835,53 @@ def test_set_grid_rejects_bad_mode(rt):
     dev.set_grid(1)
 
 
+def test_grid_long_thin_triangles(rt, orc):
+    """Triangles go into the grid cells they OVERLAP (separating axes of triangle and cell box), not the cells of
+    their bounding box: needles and long diagonal slivers through many cells, rays aimed at points on them - also
+    within 1e-4 of an edge or a corner, where a cell the registration left out would lose the hit.  The parity hook
+    walks the grid (mode 2): ids exact and distances bit-exact against the oracle, and the same through the lists."""
+    rng = np.random.default_rng(4242)
+    A = rt
+    mats = [A.LambertianModel(0.9).with_color((0.7, 0.7, 0.7)), A.Metal(0.1, 0.9)]
+    w = A.World.empty()
+    tris = []
+    for i in range(220):
+        p0 = rng.uniform(-6, 6, 3)
+        u = rng.normal(size=3); u /= np.linalg.norm(u)
+        v = rng.normal(size=3); v -= u * (u @ v); v /= np.linalg.norm(v)
+        long_e, short_e = rng.uniform(2.0, 7.0), 10.0 ** rng.uniform(-2.0, -0.3)
+        p1, p2 = p0 + u * long_e, p0 + u * rng.uniform(0.0, long_e) + v * short_e
+        tris.append((p0, p1, p2))
+        w.add_obj(A.Object(A.Triangle(tuple(p0), tuple(p1), tuple(p2)), mats[i % 2]))
+    for i in range(120):
+        w.add_obj(A.Object(A.Sphere(tuple(rng.uniform(-6, 6, 3)), float(rng.uniform(0.05, 0.2))), mats[i % 2]))
+    w.add_light(A.SkyLight())
+    n = 40000
+    k = rng.integers(0, len(tris), n)
+    T = np.array(tris)[k]                                   # (n, 3, 3)
+    b = rng.dirichlet((1.0, 1.0, 1.0), n)
+    near = rng.random(n) < 0.5                              # half the targets hug an edge or a corner
+    b[near] = np.where(rng.random((near.sum(), 3)) < 0.5, b[near] * 1e-4, b[near])
+    b /= b.sum(axis=1, keepdims=True)
+    target = (T * b[:, :, None]).sum(axis=1) + rng.normal(size=(n, 3)) * 1e-5
+    org = rng.normal(size=(n, 3)); org = org / np.linalg.norm(org, axis=1, keepdims=True) * rng.uniform(9.0, 20.0, (n, 1))
+    inside = rng.random(n) < 0.3                            # a third of the rays start inside the box
+    org[inside] = rng.uniform(-6, 6, (inside.sum(), 3))
+    d = target - org; d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([org, d], axis=1).astype(np.float32)
+    dn = np.linalg.norm(rays[:, 3:].astype(np.float64), axis=1, keepdims=True)
+    rays[:, 3:] = (rays[:, 3:] / dn).astype(np.float32)
+    ow = orc.OracleWorld(w)
+    dev = rt.default_device()
+    try:
+        for mode in (2, 0):
+            dev.set_grid(mode)
+            hits = _check_hits(w, ow, rays, seed=9, pid0=0)
+            assert hits > 0.6 * n
+    finally:
+        dev.set_grid(1)
+
+
 def test_grid_far_origins_go_to_the_rescan(rt):
     """Bounce rays that start more than 256 box-extents from the scene centre (here: off a huge ground sphere, far
     from a 10 cm cluster of 100 spheres) are not walked through the grid but resolved by the exact f64 rescan.
