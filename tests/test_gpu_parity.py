@@ -491,6 +491,24 @@ def test_split_pipeline_matches_fused(rt, name, W, H, spp, depth):
             dev.set_variant(0)
 
 
+@pytest.mark.parametrize("name,W,H,spp,depth", [("s500", 320, 184, 4, 50), ("scene_rs", 160, 96, 4, 10), ("s20k", 320, 184, 2, 8)])
+def test_rays_per_lane_on_tiled_frames(rt, name, W, H, spp, depth):
+    """1, 2, 3 or 4 rays per lane on TILED frames (width % 32 == 0, height % 8 == 0): with 1, 2 and 4 a trip of a wave is
+    part of one 32x8 tile, the level-0 launch takes its tile's list, sends 24 of a generated ray's 40 bytes through
+    the queue and numbers its survivors by slot; with 3 a trip straddles tiles and none of that applies.  Same bits."""
+    world, cam = getattr(rt.scenes, name)() if name != "s20k" else rt.scenes.s20k(width=W, height=H)
+    dev = rt.default_device()
+    a, sa = world.render(cam, W, H, depth, spp_begin=0, spp_end=spp, return_stats=True)
+    try:
+        for v in (1, 2, 3, 4):
+            dev.set_variant(v)
+            b, sb = world.render(cam, W, H, depth, spp_begin=0, spp_end=spp, return_stats=True)
+            assert np.array_equal(a, b), v
+            assert list(sa.rays_per_level[: int(sa.levels)]) == list(sb.rays_per_level[: int(sb.levels)]), v
+    finally:
+        dev.set_variant(0)
+
+
 @pytest.mark.parametrize("name,W,H,spp,depth", [("s500", 640, 360, 4, 50), ("s500", 96, 54, 8, 50), ("scene_rs", 320, 200, 4, 10),
                                                  ("cornell", 160, 120, 8, 10), ("s20k", 320, 184, 2, 8)])
 def test_wave_cull_is_exact(rt, name, W, H, spp, depth):
