@@ -809,9 +809,10 @@ __device__ __forceinline__ void scan_mtris(const SceneDev& S, RayPack<R, NS>& P,
 // of putting every listed primitive through the cone test (scan_spheres_culled: n / 64 rounds per wave, which is what
 // made the grid walk the cheaper way for primary rays above 4 096 primitives) it reads the tile's list: the primitives
 // whose bounding sphere, widened for the lens, meets the tile's pyramid.  The list is a conservative superset of what
-// any ray of the tile can hit, so everything downstream - cone test (when the bundle is narrow), per-ray cull,
-// candidate sets, exact evaluation - is what the full scan would do for those primitives, and the image is the same
-// bit for bit (tests: tile lists on / off).  n0 .. n1 = the tile's range in S.tile_idx.
+// any ray of the tile can hit, so everything downstream - per-ray cull, candidate sets, exact evaluation - is what the
+// full scan would do for those primitives, and the image is the same bit for bit (tests: tile lists on / off).
+// n0 .. n1 = the tile's range in S.tile_idx.  (narrow: also put each entry through the wave's cone test first; the
+// level kernels pass false - on lists this tight the test costs more than it removes.)
 template <int R, int NS, int LISTS>
 __device__ __forceinline__ void scan_tile_list(const SceneDev& S, RayPack<R, NS>& P, const Bundle& B, bool narrow,
                                                uint32_t n0, uint32_t n1) {
