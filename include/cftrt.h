@@ -183,6 +183,15 @@ int cftrt_scene_set_lights(cftrt_scene* scene, const cftrt_light* lights, int64_
                            const double* lsph_center, const double* lsph_radius, int64_t n_lsph,
                            const double* ltri_p0, const double* ltri_p1, const double* ltri_p2,
                            int64_t n_ltri);
+/* Square::from_points (src/object.rs:169-174): its two triangles (p0,p1,p2), (p1,p2,p3) need not share a plane, and
+ * Square::hit_info is `tri0.hit_info(ray).or(tri1.hit_info(ray))` (object.rs:192): the second triangle counts only
+ * where the first is NOT hit, whatever the two distances (Square::new squares are planar and share only the diagonal,
+ * so for them the rule is the closest of the two - they need no entry here).  tri_first[i] = index of the triangle
+ * (among those of cftrt_scene_set_triangles, < i, same obj_id) that shadows triangle i this way, -1 for every other
+ * triangle; ltri_first likewise over the light-shape triangles of cftrt_scene_set_lights (both triangles in one
+ * light).  Optional; n_tri / n_ltri must equal the triangle counts at commit (0 with NULL: no pairs of that kind). */
+int cftrt_scene_set_triangle_pairs(cftrt_scene* scene, const int32_t* tri_first, int64_t n_tri,
+                                   const int32_t* ltri_first, int64_t n_ltri);
 /* Spheres with |radius| >= this are tested in f64 for every ray (default 25). */
 int cftrt_scene_set_precise_radius(cftrt_scene* scene, double radius);
 /* Uploads the flattened scene to HBM.  No setter may be called afterwards. */
@@ -205,15 +214,17 @@ int cftrt_render_device(cftrt_scene* scene, const cftrt_camera* cam, uint32_t wi
                         uint64_t seed, void* accum_device, cftrt_stats* stats);
 
 /* The same render for callers that cannot allocate.  It has NO counterpart in the reference; it exists for hosts
- * that must not call hipMalloc at this point: code under HIP graph capture, tight serving loops, harnesses that
- * forbid allocation.  Same arguments and result as cftrt_render_device (for a sample range that cftrt_render_device
+ * that must not call hipMalloc at this point: hosts with a HIP graph capture in progress on ANOTHER stream (an
+ * allocation would invalidate the capture; the call itself synchronises its own stream and reads level counters back,
+ * so it cannot be captured into a graph), tight serving loops, harnesses that forbid allocation.  Same arguments and result as cftrt_render_device (for a sample range that cftrt_render_device
  * renders in one pass the images are identical bit for bit; k_resolve adds samples one by one, so the cut into
  * passes does not change the sum either), but the pass workspace (ray queues, radiance slots, level counters) is a
  * file-scope device array of CFTRT_STATIC_SCRATCH_BYTES (256 MiB) that every GPU the library runs on holds until the
  * process ends; the call makes no hipMalloc/hipFree and creates no event (cftrt_stats: ms_total only, the per-kernel
  * times stay 0).  Limit: one sample of the image must fit - width*height*92 bytes (148 with PhongModel materials,
- * +32/64 in the split pipeline) <= 256 MiB less 8 KiB, i.e. up to 2.91 M pixels (1920x1080 fits, 3840x2160 does
- * not): CFTRT_ERR_LIMIT otherwise.  Larger sample counts run as several passes.  All calls on one GPU share that
+ * +40/80 in the split pipeline) <= 256 MiB less the 380 KiB the library keeps for the level counters, the slack
+ * of the segmented queues and the alignment of its carves (kStaticHeader + 4 KiB in cftrt.hip), i.e. up to 2.91 M
+ * pixels (1920x1080 fits, 3840x2160 does not): CFTRT_ERR_LIMIT otherwise.  Larger sample counts run as several passes.  All calls on one GPU share that
  * GPU's array (whatever the ctx): calls that overlap in time on one GPU race; the library clears the counters it
  * needs at the start of every pass, nothing else must start at zero. */
 int cftrt_render_device_static(cftrt_scene* scene, const cftrt_camera* cam, uint32_t width,
@@ -251,7 +262,24 @@ int cftrt_generate(cftrt_ctx* ctx, const cftrt_camera* cam, uint32_t width, uint
 int cftrt_intersect(cftrt_scene* scene, const float* rays, uint64_t n, uint64_t seed,
                     uint64_t pid0, uint32_t level, uint32_t role, int32_t* out_id, double* out_t,
                     float* out_normal, float* out_point, int32_t* out_outward);
-/* World::trace per path: out_rgb = n x 3 floats for path ids [pid0, pid0+n). */
+/* Ray::hit as the PRODUCTION level kernel finds it (cftrt_intersect above runs a one-ray-per-lane form of the same
+ * code): ONE launch of the fused level kernel exactly as a render call issues it at trace level `level` - the
+ * instance for the scene's kind, the rays per lane of cftrt_ctx_set_variant, wave cull, grid walk, per-tile lists as
+ * the ctx has them - as the pass's last level (nothing is appended), returning the winner of every scan of every ray.
+ *   rays != NULL: n caller rays (n x 6 floats, unit directions) are the level's input queue; path id of ray i =
+ *     pid0 + i.  With level >= 1 and a grid the walk instances run, with level 0 the cone-cull / list instances;
+ *     fewer than 2^17 (grid) / 2^19 rays with variant 0 run the tail kernel, as in a render call.
+ *   rays == NULL: level must be 0 and [pid0, pid0 + n) whole samples of the width x height image of `cam`: the
+ *     launch generates its rays itself (Camera::emit_rays; the rays cftrt_generate returns for the same ids), in
+ *     32x8-pixel tiles with per-tile lists where a render call would use them.
+ * *out_scans = scans per ray (2 for a scene with moving objects and lights: [0] the lights' `looked` scan, keyed by
+ * the first looking light's index, [1] trace's own, keyed by the number of lights; else 1).  out_id[i * scans + k] =
+ * object index or -1, out_t[i * scans + k] = the exact f64 distance (+inf on a miss).  Not in the split pipeline. */
+int cftrt_level_hits(cftrt_scene* scene, const cftrt_camera* cam, uint32_t width, uint32_t height,
+                     const float* rays, uint64_t n, uint64_t seed, uint64_t pid0, uint32_t level,
+                     int32_t* out_id, double* out_t, int32_t* out_scans);
+/* World::trace per path: out_rgb = n x 3 floats for path ids [pid0, pid0+n).  Whole samples of the image
+ * (pid0 and n multiples of width*height) run exactly as cftrt_render runs them (tiled queue, per-tile lists). */
 int cftrt_trace_paths(cftrt_scene* scene, const cftrt_camera* cam, uint32_t width, uint32_t height,
                       uint64_t pid0, uint64_t n, uint32_t max_depth, uint64_t seed, int jitter,
                       float* out_rgb, cftrt_stats* stats);

@@ -218,6 +218,9 @@ struct Square : Shape {  // object.rs:141-197
     V p3 = add(add(center, x2), y2);
     return Square(Triangle(p0, p1, p2), Triangle(p2, p3, p0));
   }
+  static Square from_points(V p0, V p1, V p2, V p3) {  // :169-174
+    return Square(Triangle(p0, p1, p2), Triangle(p1, p2, p3));
+  }
   bool hit_info(const Ray& ray, HitInfo* out) const override {  // :191-193 tri0.or(tri1)
     HitInfo a, b;
     bool ha = tri0.hit_info(ray, &a);
@@ -710,6 +713,14 @@ int orc_add_triangle(void* w, const double* p0, const double* p1, const double* 
 }
 int orc_add_square(void* w, const double* c, const double* x, const double* y, double l, int mat, const double* mv) {
   return push_obj((World*)w, new Square(Square::make(pv(c), pv(x), pv(y), l)), mat, mv);
+}
+int orc_add_square_points(void* w, const double* p0, const double* p1, const double* p2, const double* p3, int mat,
+                          const double* mv) {
+  return push_obj((World*)w, new Square(Square::from_points(pv(p0), pv(p1), pv(p2), pv(p3))), mat, mv);
+}
+int orc_add_light_square_points(void* w, const double* p0, const double* p1, const double* p2, const double* p3) {
+  ((World*)w)->lights.emplace_back(new LightShape(new Square(Square::from_points(pv(p0), pv(p1), pv(p2), pv(p3)))));
+  return 0;
 }
 int orc_add_cube(void* w, const double* c, const double* x, const double* y, double l, int mat, const double* mv) {
   return push_obj((World*)w, new Cube(pv(c), pv(x), pv(y), l), mat, mv);

@@ -67,6 +67,7 @@ SYMBOLS = [
     ("cftrt_scene_set_materials", C.c_int, [_P, C.POINTER(cftrt_material), C.c_int64]),
     ("cftrt_scene_set_lights", C.c_int, [_P, C.POINTER(cftrt_light), C.c_int64, _D, _D, C.c_int64, _D, _D, _D,
                                          C.c_int64]),
+    ("cftrt_scene_set_triangle_pairs", C.c_int, [_P, _I, C.c_int64, _I, C.c_int64]),
     ("cftrt_scene_set_precise_radius", C.c_int, [_P, C.c_double]),
     ("cftrt_scene_commit", C.c_int, [_P]),
     ("cftrt_render", C.c_int, [_P, C.POINTER(cftrt_camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
@@ -83,6 +84,8 @@ SYMBOLS = [
                                  C.c_uint64, C.c_int, _F]),
     ("cftrt_intersect", C.c_int, [_P, _F, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _I, _D, _F,
                                   _F, _I]),
+    ("cftrt_level_hits", C.c_int, [_P, C.POINTER(cftrt_camera), C.c_uint32, C.c_uint32, _F, C.c_uint64, C.c_uint64,
+                                   C.c_uint64, C.c_uint32, _I, _D, _I]),
     ("cftrt_trace_paths", C.c_int, [_P, C.POINTER(cftrt_camera), C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64,
                                     C.c_uint32, C.c_uint64, C.c_int, _F, C.POINTER(cftrt_stats)]),
     ("cftrt_resolve_rgb8", C.c_int, [_P, _F, C.c_uint64, C.c_double, C.POINTER(C.c_uint8)]),

@@ -77,16 +77,22 @@ class Square:
         p3 = v_add(v_add(center, x2), y2)
         self.tri0 = Triangle(p0, p1, p2)
         self.tri1 = Triangle(p2, p3, p0)
+        self.or_pair = False
 
     @classmethod
     def from_points(cls, p0, p1, p2, p3):  # object.rs:169-174
-        """Not flattened to the device.  The reference's Square::hit_info is `tri0.or(tri1)` (object.rs:192): tri0 wins
-        whenever it is hit, even where tri1 is nearer.  For Square::new that never differs from the closest of the two
-        (coplanar triangles that share only the diagonal); for from_points, whose triangles (p0,p1,p2) and (p1,p2,p3)
-        overlap or leave the plane, it does, and the device's closest-hit rule over triangles would give other
-        results.  Build the two triangles as separate objects, or use Square.new."""
-        raise NotImplementedError("Square.from_points has no device counterpart (tri0-first rule, object.rs:192); "
-                                  "use Square(center, x, y, len) or two Triangle objects")
+        """tri0 = (p0, p1, p2), tri1 = (p1, p2, p3).  The reference's Square::hit_info is `tri0.or(tri1)`
+        (object.rs:192): tri0 wins whenever it is hit, even where tri1 is nearer.  For Square::new that never differs
+        from the closest of the two (coplanar triangles that share only the diagonal); for from_points, whose triangles
+        may overlap or leave the plane, it does - the pair is flagged (`or_pair`) and the device's exact evaluation
+        ignores tri1 wherever tri0 is hit (cftrt_scene_set_triangle_pairs)."""
+        sq = cls.__new__(cls)
+        sq._ctor = None
+        sq._points = (_v(p0), _v(p1), _v(p2), _v(p3))
+        sq.tri0 = Triangle(p0, p1, p2)
+        sq.tri1 = Triangle(p1, p2, p3)
+        sq.or_pair = True
+        return sq
 
     def _flatten(self):
         return [], [(self.tri0.p0, self.tri0.p1, self.tri0.p2), (self.tri1.p0, self.tri1.p1, self.tri1.p2)]
@@ -474,14 +480,16 @@ class World:
     def flatten(self):
         f = FlatScene()
         sc, sr, smv, sobj, smat = [], [], [], [], []
-        tp0, tp1, tp2, tmv, tobj, tmat = [], [], [], [], [], []
+        tp0, tp1, tp2, tmv, tobj, tmat, tfirst = [], [], [], [], [], [], []
         mats = []
         for oi, o in enumerate(self.objects):
             mats.append(o.material._row())   # one table row per object (Arc<dyn Material> per object)
             sph, tri = o.shape._flatten()
             for c, r in sph:
                 sc.append(c); sr.append(r); smv.append(o.moving_to); sobj.append(oi); smat.append(oi)
-            for a, b, c in tri:
+            pair = getattr(o.shape, "or_pair", False)   # Square.from_points: its second triangle is shadowed by its first
+            for j, (a, b, c) in enumerate(tri):
+                tfirst.append(len(tp0) - 1 if (pair and j == 1) else -1)
                 tp0.append(a); tp1.append(b); tp2.append(c); tmv.append(o.moving_to); tobj.append(oi); tmat.append(oi)
         f.sph_center = np.array(sc, np.float64).reshape(-1, 3)
         f.sph_radius = np.array(sr, np.float64)
@@ -494,8 +502,9 @@ class World:
         f.tri_moving = np.array(tmv, np.float64).reshape(-1, 3)
         f.tri_obj = np.array(tobj, np.int32)
         f.tri_mat = np.array(tmat, np.int32)
+        f.tri_first = np.array(tfirst, np.int32)
         f.materials = mats
-        lrows, lsc, lsr, lt0, lt1, lt2 = [], [], [], [], [], []
+        lrows, lsc, lsr, lt0, lt1, lt2, ltfirst = [], [], [], [], [], [], []
         for l in self.lights:
             row = dict(kind=l.kind, sph_begin=0, sph_count=0, tri_begin=0, tri_count=0, v=(0.0, 0.0, 0.0),
                        color=(1.0, 1.0, 1.0))
@@ -504,7 +513,9 @@ class World:
                 row.update(sph_begin=len(lsr), sph_count=len(sph), tri_begin=len(lt0), tri_count=len(tri))
                 for c, r in sph:
                     lsc.append(c); lsr.append(r)
-                for a, b, c in tri:
+                pair = getattr(l.shape, "or_pair", False)
+                for j, (a, b, c) in enumerate(tri):
+                    ltfirst.append(len(lt0) - 1 if (pair and j == 1) else -1)
                     lt0.append(a); lt1.append(b); lt2.append(c)
             elif l.kind == 2:
                 row.update(v=l.pos, color=l.light_color)
@@ -517,6 +528,7 @@ class World:
         f.ltri_p0 = np.array(lt0, np.float64).reshape(-1, 3)
         f.ltri_p1 = np.array(lt1, np.float64).reshape(-1, 3)
         f.ltri_p2 = np.array(lt2, np.float64).reshape(-1, 3)
+        f.ltri_first = np.array(ltfirst, np.int32)
         return f
 
     def commit(self, device=None, precise_radius=None):
@@ -552,6 +564,9 @@ class World:
             dev.check(lib.cftrt_scene_set_lights(h, lt, len(f.lights), _dptr(f.lsph_center), _dptr(f.lsph_radius),
                                                  len(f.lsph_radius), _dptr(f.ltri_p0), _dptr(f.ltri_p1),
                                                  _dptr(f.ltri_p2), len(f.ltri_p0)))
+            if (f.tri_first >= 0).any() or (f.ltri_first >= 0).any():
+                dev.check(lib.cftrt_scene_set_triangle_pairs(h, _iptr(f.tri_first), len(f.tri_first),
+                                                             _iptr(f.ltri_first), len(f.ltri_first)))
             dev.check(lib.cftrt_scene_commit(h))
         except Exception:
             lib.cftrt_scene_destroy(h)
@@ -608,6 +623,25 @@ class World:
         dev.check(dev.lib.cftrt_intersect(h, _fptr(rays), n, seed, pid0, level, role, _iptr(ids), _dptr(t),
                                           _fptr(nrm), _fptr(pt), _iptr(outward)))
         return (ids, t, nrm, pt, outward) if with_outward else (ids, t, nrm, pt)
+
+    def level_hits(self, rays=None, camera=None, width=0, height=0, n=None, seed=0, pid0=0, level=0, device=None):
+        """Ray::hit as the production level kernel finds it (cftrt_level_hits): one launch of the fused level kernel at
+        trace level `level`, on caller rays (n x 6) or, with rays=None, on the primary rays it generates itself for
+        whole samples of the image.  Returns (object ids, f64 distances), each n x scans."""
+        h = self.commit(device)
+        dev = self._dev
+        if rays is not None:
+            rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+            n = len(rays)
+        pod = camera._pod() if camera is not None else None
+        ids = np.empty((n, 2), np.int32)
+        t = np.empty((n, 2), np.float64)
+        scans = C.c_int32(0)
+        dev.check(dev.lib.cftrt_level_hits(h, C.byref(pod) if pod is not None else None, int(width), int(height),
+                                           _fptr(rays) if rays is not None else None, n, seed, pid0, level,
+                                           _iptr(ids), _dptr(t), C.byref(scans)))
+        k = scans.value
+        return ids.reshape(-1)[: n * k].reshape(n, k).copy(), t.reshape(-1)[: n * k].reshape(n, k).copy()
 
     def trace_paths(self, camera, width, height, pid0, n, depth, seed=0x5EED0002, jitter=True, device=None):
         h = self.commit(device)

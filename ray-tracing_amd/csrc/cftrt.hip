@@ -36,7 +36,7 @@ struct cftrt_ctx {
   bool tiles_active = false;   // the lists in tile_off / tile_idx are those of the render call in progress
   int n_cu = 256;
   // grow-only workspace
-  DevBuf qa[2], qb[2], qc[2], h0[2], h1[2], ht[2], rad, pqa, pqb, pqc, pqd, counts, accum_tmp, misc, tile_rng, tile_cnt, tile_off, tile_idx;
+  DevBuf qa[2], qb[2], qc[2], h0[1 + CFT_MAX_LOOK], h1[1 + CFT_MAX_LOOK], ht[1 + CFT_MAX_LOOK], rad, pqa, pqb, pqc, pqd, counts, accum_tmp, misc, tile_rng, tile_cnt, tile_off, tile_idx;
   uint32_t* host_counts = nullptr;   // pinned
   std::vector<hipEvent_t> events;
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
@@ -56,24 +56,25 @@ struct RcclApi {
   int (*CommDestroy)(void*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
-static RcclApi* rccl_api(std::string* err) {
-  static RcclApi api;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-      if (api.lib) break;
-    }
-    if (api.lib) {
-      api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
-      api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
-      api.Reduce = (decltype(api.Reduce))dlsym(api.lib, "ncclReduce");
-      api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
-      api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
-      if (!api.GetUniqueId || !api.CommInitRank || !api.Reduce || !api.CommDestroy) { dlclose(api.lib); api.lib = nullptr; }
-    }
+// Loaded once per process, whichever thread asks first (cftrt_comm_* may be called from one host thread per GPU).
+static RcclApi load_rccl() {
+  RcclApi api;
+  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (api.lib) break;
   }
+  if (api.lib) {
+    api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
+    api.Reduce = (decltype(api.Reduce))dlsym(api.lib, "ncclReduce");
+    api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+    api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+    if (!api.GetUniqueId || !api.CommInitRank || !api.Reduce || !api.CommDestroy) { dlclose(api.lib); api.lib = nullptr; }
+  }
+  return api;
+}
+static const RcclApi* rccl_api(std::string* err) {
+  static const RcclApi api = load_rccl();   // (a function-local static: initialised exactly once, thread-safe since C++11)
   if (!api.lib) { if (err) *err = "librccl.so.1 could not be loaded (dlopen) or lacks the nccl* entry points"; return nullptr; }
   return &api;
 }
@@ -109,6 +110,9 @@ struct cftrt_scene {
   std::vector<cftrt_material> mats;
   std::vector<cftrt_light> lights;
   std::vector<double> lsph, ltri;      // 4 / 9 per prim
+  std::vector<int32_t> tri_first, ltri_first;   // Square::from_points pairs (cftrt_scene_set_triangle_pairs); empty: none
+  int n_look = 0;                      // lights that look (SkyLight, LightShape)
+  bool multi_look = false;             // moving scene with several of them: one `looked` scan per light (split pipeline)
   std::vector<void*> dev_allocs;
   SceneDev dev;
 };
@@ -214,11 +218,13 @@ void cftrt_ctx_destroy(cftrt_ctx* ctx) {
   DeviceGuard guard(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->comm) (void)cftrt_comm_destroy(ctx);
-  DevBuf* bufs[] = {&ctx->qa[0], &ctx->qa[1], &ctx->qb[0], &ctx->qb[1], &ctx->qc[0], &ctx->qc[1], &ctx->h0[0],
-                    &ctx->h0[1], &ctx->h1[0], &ctx->h1[1], &ctx->ht[0], &ctx->ht[1], &ctx->rad, &ctx->pqa, &ctx->pqb, &ctx->pqc,
+  DevBuf* bufs[] = {&ctx->qa[0], &ctx->qa[1], &ctx->qb[0], &ctx->qb[1], &ctx->qc[0], &ctx->qc[1], &ctx->rad, &ctx->pqa, &ctx->pqb, &ctx->pqc,
                     &ctx->pqd, &ctx->counts, &ctx->accum_tmp, &ctx->misc, &ctx->tile_rng, &ctx->tile_cnt, &ctx->tile_off, &ctx->tile_idx};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
+  for (int k = 0; k < 1 + CFT_MAX_LOOK; ++k)
+    for (DevBuf* b : {&ctx->h0[k], &ctx->h1[k], &ctx->ht[k]})
+      if (b->p) (void)hipFree(b->p);
   for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
   if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);
   if (ctx->ev_t1) (void)hipEventDestroy(ctx->ev_t1);
@@ -388,6 +394,21 @@ int cftrt_scene_set_lights(cftrt_scene* s, const cftrt_light* lights, int64_t n_
   return CFTRT_OK;
 }
 
+int cftrt_scene_set_triangle_pairs(cftrt_scene* s, const int32_t* tri_first, int64_t n_tri, const int32_t* ltri_first,
+                                   int64_t n_ltri) {
+  if (!s) return CFTRT_ERR_INVALID;
+  if (s->committed) return fail(s->ctx, CFTRT_ERR_STATE, "scene already committed");
+  if (n_tri < 0 || n_ltri < 0 || (n_tri > 0 && !tri_first) || (n_ltri > 0 && !ltri_first))
+    return fail(s->ctx, CFTRT_ERR_INVALID, "set_triangle_pairs: null pointer or negative n");
+  for (int64_t i = 0; i < n_tri; ++i)
+    if (tri_first[i] < -1 || tri_first[i] >= i) return fail(s->ctx, CFTRT_ERR_INVALID, "set_triangle_pairs: tri_first[i] must be -1 or an earlier triangle");
+  for (int64_t i = 0; i < n_ltri; ++i)
+    if (ltri_first[i] < -1 || ltri_first[i] >= i) return fail(s->ctx, CFTRT_ERR_INVALID, "set_triangle_pairs: ltri_first[i] must be -1 or an earlier triangle");
+  s->tri_first.assign(tri_first, tri_first + n_tri);
+  s->ltri_first.assign(ltri_first, ltri_first + n_ltri);
+  return CFTRT_OK;
+}
+
 int cftrt_scene_set_precise_radius(cftrt_scene* s, double radius) {
   if (!s) return CFTRT_ERR_INVALID;
   if (s->committed) return fail(s->ctx, CFTRT_ERR_STATE, "scene already committed");
@@ -444,6 +465,28 @@ int cftrt_scene_commit(cftrt_scene* s) {
     if (s->sph_mat[i] >= nm) return fail(ctx, CFTRT_ERR_INVALID, "sphere mat_id beyond the material table");
   for (int i = 0; i < nt; ++i)
     if (s->tri_mat[i] >= nm) return fail(ctx, CFTRT_ERR_INVALID, "triangle mat_id beyond the material table");
+  // Square::from_points pairs: one entry per triangle (or none at all), the shadowing triangle in the same object
+  if (!s->tri_first.empty() && (int)s->tri_first.size() != nt) return fail(ctx, CFTRT_ERR_INVALID, "set_triangle_pairs: n_tri differs from the triangle count");
+  if (!s->ltri_first.empty() && s->ltri_first.size() * 9 != s->ltri.size()) return fail(ctx, CFTRT_ERR_INVALID, "set_triangle_pairs: n_ltri differs from the light-triangle count");
+  int any_pairs = 0;
+  for (size_t i = 0; i < s->tri_first.size(); ++i)
+    if (s->tri_first[i] >= 0) {
+      if (s->tri_obj[s->tri_first[i]] != s->tri_obj[i]) return fail(ctx, CFTRT_ERR_INVALID, "set_triangle_pairs: a pair spans two objects");
+      any_pairs = 1;
+    }
+  for (size_t i = 0; i < s->ltri_first.size(); ++i) {
+    if (s->ltri_first[i] < 0) continue;
+    bool same = false;   // both triangles inside one light's range
+    for (const cftrt_light& L : s->lights)
+      if (L.kind == CFTRT_LIGHT_SHAPE && (int64_t)i >= L.tri_begin && (int64_t)i < L.tri_begin + (int64_t)L.tri_count && s->ltri_first[i] >= L.tri_begin) same = true;
+    if (!same) return fail(ctx, CFTRT_ERR_INVALID, "set_triangle_pairs: a light-triangle pair spans two lights");
+    any_pairs = 1;
+  }
+  std::vector<int32_t> tri_first(s->tri_first), ltri_first(s->ltri_first);
+  tri_first.resize((size_t)nt, -1);
+  ltri_first.resize(s->ltri.size() / 9, -1);
+  s->n_look = 0;
+  for (const cftrt_light& L : s->lights) if (L.kind == CFTRT_LIGHT_SKY || L.kind == CFTRT_LIGHT_SHAPE) s->n_look++;
 
   std::vector<float4> sphF, msphF, msphB, triF, mtriF;
   double rb_max = 0.;   // largest swept-bound radius of a moving sphere
@@ -787,6 +830,9 @@ int cftrt_scene_commit(cftrt_scene* s) {
   if ((rc = upload(s, s->sph_mv, &D.sphMvD))) return rc;
   if ((rc = upload(s, s->tri_p, &D.triD))) return rc;
   if ((rc = upload(s, s->tri_mv, &D.triMvD))) return rc;
+  if ((rc = upload(s, tri_first, &D.tri_first))) return rc;
+  if ((rc = upload(s, ltri_first, &D.ltri_first))) return rc;
+  D.any_pairs = any_pairs;
   if ((rc = upload(s, prim_obj, &D.prim_obj))) return rc;
   if ((rc = upload(s, prim_mat, &D.prim_mat))) return rc;
   if ((rc = upload(s, mats, &D.mats))) return rc;
@@ -803,6 +849,9 @@ int cftrt_scene_commit(cftrt_scene* s) {
   D.n_mat = nm;
   D.n_lights = (int)lights.size();
   D.any_motion = any_motion;
+  s->multi_look = any_motion && s->n_look >= 2;
+  if (s->multi_look && s->n_look > CFT_MAX_LOOK)
+    return fail(ctx, CFTRT_ERR_LIMIT, "a scene with moving objects may hold at most 8 lights that look (SkyLight, LightShape)");
   D.prec_motion = prec_motion;
   D.n_phong_mats = n_phong;
   D.gnx = G.n[0]; D.gny = G.n[1]; D.gnz = G.n[2];
@@ -953,7 +1002,7 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
                                uint32_t max_depth, uint64_t pid_base, uint32_t k0, uint32_t k1, bool two_scans,
                                uint32_t role0, uint32_t role1, QueueDev qout, Rad3* rad, PhongQueueDev pq,
                                uint32_t* phong_counts, uint32_t* xstats, uint32_t P, const GenArgs* gen, uint32_t in_D,
-                               uint32_t* out_D_io) {
+                               uint32_t* out_D_io, double* dbg_t = nullptr, int32_t* dbg_prim = nullptr) {
   // *out_D_io on entry: nonzero = the caller wants the output queue sharded; on return: the segment stride used (0: dense)
   const bool want_shards = *out_D_io != 0;
   *out_D_io = 0;
@@ -972,7 +1021,7 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
     blocks = std::max<uint64_t>(1, std::min<uint64_t>(blocks, (uint64_t)ctx->n_cu * 8));
 #define CFT_TAIL(NN, LL) hipLaunchKernelGGL((k_trace_tail<2, NN, LL>), dim3((uint32_t)blocks), dim3(CFT_BLOCK), 0, st, S, q, \
                                             counts, level, max_depth, pid_base, k0, k1, role0, role1, qout, rad, pq,       \
-                                            phong_counts, xstats)
+                                            phong_counts, xstats, dbg_t, dbg_prim)
     if (two_scans) CFT_TAIL(2, 3);
     else if (lean) CFT_TAIL(1, 0);
     else CFT_TAIL(1, 3);
@@ -993,7 +1042,7 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
     *out_D_io = out_D;
   }
   LevelArgs LA{S, q, counts, level, max_depth, pid_base, k0, k1, role0, role1, qout, rad, pq, phong_counts, xstats,
-               gen ? *gen : no_gen, in_D, out_k, out_D};
+               gen ? *gen : no_gen, in_D, out_k, out_D, dbg_t, dbg_prim};
 #define CFT_LAUNCH(RR, NN, LL)                                                                                          \
   do {                                                                                                                  \
     if (gen) hipLaunchKernelGGL((k_trace_level<RR, NN, LL, true>), dim3(g), dim3(CFT_BLOCK), dyn_lds, st, LA);           \
@@ -1077,7 +1126,8 @@ static const size_t kQueueSlack = (size_t)CFT_SHARDS * 2 * 64 * 4 + 256;   // sl
 // Device buffers of one pass (P paths): the ray queues, the radiance slots, the Phong queue, the level counters.
 struct PassBufs {
   QueueDev q[2];
-  HitDev hA, hB;
+  LookRecs hA;   // records of the `looked` scan(s): one set, or one per looking light (scene->multi_look)
+  HitDev hB;     // records of trace's own scan (= hA.r[0] unless the scene has motion AND lights)
   PhongQueueDev pq;
   Rad3* rad;
   uint32_t* counts;
@@ -1089,15 +1139,23 @@ static const size_t kStampWord = 2 * CFTRT_MAX_LEVELS + 2 + 8;   // even: 8-byte
 static_assert(kStampWord % 2 == 0, "stamp sums are 64-bit words");   // [0..L] level counts, [L+1..2L+1] phong counts, then: second evaluations, rescans, k_trace_finish's queue cursor
 static_assert(CFTRT_MAX_LEVELS == CFTRT_MAX_LEVELS_DEV, "kernels.h and cftrt.h disagree on the level limit");
 
-static uint64_t bytes_per_path(const cftrt_ctx* ctx, const SceneDev& S) {
+// A pass runs the split pipeline (k_intersect -> hit records -> k_shade) when the ctx asks for it, and always for a
+// moving scene with several lights that look: each of those lights then gets a `looked` scan of its own.
+static bool pass_split(const cftrt_ctx* ctx, const cftrt_scene* s) { return ctx->split || s->multi_look; }
+static int pass_look_sets(const cftrt_scene* s) { return s->multi_look ? s->n_look : 1; }
+
+static uint64_t bytes_per_path(const cftrt_ctx* ctx, const cftrt_scene* s) {
+  const SceneDev& S = s->dev;
   const bool two_scans = S.any_motion && S.n_lights > 0;
-  return 80 + 12 + (ctx->split ? (two_scans ? 80 : 40) : 0) + (S.n_phong_mats ? 56 : 0);
+  return 80 + 12 + (pass_split(ctx, s) ? 40ull * (pass_look_sets(s) + (two_scans ? 1 : 0)) : 0) + (S.n_phong_mats ? 56 : 0);
 }
 
 // From the ctx's grow-only hipMalloc'ed workspace.
-static int bufs_from_ctx(cftrt_ctx* ctx, const SceneDev& S, uint32_t P, PassBufs* B) {
+static int bufs_from_ctx(cftrt_ctx* ctx, const cftrt_scene* s, uint32_t P, PassBufs* B) {
+  const SceneDev& S = s->dev;
   const bool phong = S.n_phong_mats > 0;
   const bool two_scans = S.any_motion && S.n_lights > 0;
+  const int nA = pass_look_sets(s);
   int rc;
   const size_t Q = (size_t)P + kQueueSlack;   // a sharded queue: CFT_SHARDS segments, each rounded up to whole trips
   for (int k = 0; k < 2; ++k) {
@@ -1105,7 +1163,7 @@ static int bufs_from_ctx(cftrt_ctx* ctx, const SceneDev& S, uint32_t P, PassBufs
     if ((rc = ensure(ctx, ctx->qb[k], Q * 16))) return rc;
     if ((rc = ensure(ctx, ctx->qc[k], Q * 8))) return rc;
   }
-  for (int k = 0; ctx->split && k < (two_scans ? 2 : 1); ++k) {   // hit records: split pipeline only
+  for (int k = 0; pass_split(ctx, s) && k < nA + (two_scans ? 1 : 0); ++k) {   // hit records: split pipeline only
     if ((rc = ensure(ctx, ctx->h0[k], (size_t)P * 16))) return rc;
     if ((rc = ensure(ctx, ctx->h1[k], (size_t)P * 16))) return rc;
     if ((rc = ensure(ctx, ctx->ht[k], (size_t)P * 8))) return rc;
@@ -1119,8 +1177,10 @@ static int bufs_from_ctx(cftrt_ctx* ctx, const SceneDev& S, uint32_t P, PassBufs
   }
   if ((rc = ensure(ctx, ctx->counts, kCountWords * 4))) return rc;
   for (int k = 0; k < 2; ++k) B->q[k] = QueueDev{(float4*)ctx->qa[k].p, (float4*)ctx->qb[k].p, (float2*)ctx->qc[k].p};
-  B->hA = HitDev{(float4*)ctx->h0[0].p, (float4*)ctx->h1[0].p, (double*)ctx->ht[0].p};
-  B->hB = two_scans ? HitDev{(float4*)ctx->h0[1].p, (float4*)ctx->h1[1].p, (double*)ctx->ht[1].p} : B->hA;
+  memset(&B->hA, 0, sizeof B->hA);
+  B->hA.n = nA;
+  for (int k = 0; k < nA; ++k) B->hA.r[k] = HitDev{(float4*)ctx->h0[k].p, (float4*)ctx->h1[k].p, (double*)ctx->ht[k].p};
+  B->hB = two_scans ? HitDev{(float4*)ctx->h0[nA].p, (float4*)ctx->h1[nA].p, (double*)ctx->ht[nA].p} : B->hA.r[0];
   B->pq = PhongQueueDev{(float4*)ctx->pqa.p, (float4*)ctx->pqb.p, (float4*)ctx->pqc.p, (uint2*)ctx->pqd.p};
   B->rad = (Rad3*)ctx->rad.p;
   B->counts = (uint32_t*)ctx->counts.p;
@@ -1130,7 +1190,8 @@ static int bufs_from_ctx(cftrt_ctx* ctx, const SceneDev& S, uint32_t P, PassBufs
 // Carved out of the static array (`base` = its device address on the ctx's device, from hipGetSymbolAddress).
 // No allocation; fails if the pass does not fit.
 static const size_t kStaticHeader = kCountWords * 4 + 2 * kQueueSlack * 40 + 4096;   // the counters, the queues' slack, and room for the 256-byte alignment of each carve
-static int bufs_from_static(cftrt_ctx* ctx, const SceneDev& S, uint32_t P, PassBufs* B) {
+static int bufs_from_static(cftrt_ctx* ctx, const cftrt_scene* s, uint32_t P, PassBufs* B) {
+  const SceneDev& S = s->dev;
   const bool phong = S.n_phong_mats > 0;
   const bool two_scans = S.any_motion && S.n_lights > 0;
   unsigned char* base = ctx->static_scratch;
@@ -1151,10 +1212,14 @@ static int bufs_from_static(cftrt_ctx* ctx, const SceneDev& S, uint32_t P, PassB
     B->q[k].c = (float2*)carve(Q * 8);
   }
   B->rad = (Rad3*)carve((size_t)P * 12);
-  B->hA = B->hB = HitDev{nullptr, nullptr, nullptr};
-  if (ctx->split) {
-    B->hA = HitDev{(float4*)carve((size_t)P * 16), (float4*)carve((size_t)P * 16), (double*)carve((size_t)P * 8)};
-    B->hB = two_scans ? HitDev{(float4*)carve((size_t)P * 16), (float4*)carve((size_t)P * 16), (double*)carve((size_t)P * 8)} : B->hA;
+  memset(&B->hA, 0, sizeof B->hA);
+  B->hA.n = 1;
+  B->hB = HitDev{nullptr, nullptr, nullptr};
+  if (pass_split(ctx, s)) {
+    B->hA.n = pass_look_sets(s);
+    for (int k = 0; k < B->hA.n; ++k)
+      B->hA.r[k] = HitDev{(float4*)carve((size_t)P * 16), (float4*)carve((size_t)P * 16), (double*)carve((size_t)P * 8)};
+    B->hB = two_scans ? HitDev{(float4*)carve((size_t)P * 16), (float4*)carve((size_t)P * 16), (double*)carve((size_t)P * 8)} : B->hA.r[0];
   }
   B->pq = PhongQueueDev{nullptr, nullptr, nullptr, nullptr};
   if (phong)
@@ -1173,7 +1238,7 @@ static int build_tile_lists(cftrt_scene* s, const CamDev& C, const cftrt_camera*
   ctx->tiles_active = false;
   const SceneDev& S = s->dev;
   const uint32_t n = (uint32_t)(S.n_sphF + S.n_msph + S.n_triF);
-  if (!ctx->tile_lists || ctx->split || n < 64 || C.width % 32u || C.height % 8u) return CFTRT_OK;
+  if (!ctx->tile_lists || pass_split(ctx, s) || n < 64 || C.width % 32u || C.height % 8u) return CFTRT_OK;
   const uint32_t ntx = C.width / 32u, nty = C.height / 8u, nt = ntx * nty;
   if (ntx > 65535u || nty > 65535u) return CFTRT_OK;
   {   // lens radius against the distance of the viewport plane (the blur a |1 - depth / fd| that k_tile_bin widens a primitive by stays small against it)
@@ -1223,7 +1288,8 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
   const bool two_scans = S.any_motion && S.n_lights > 0;   // `looked` and trace each draw their own motion times
   int rc;
   PassBufs B;
-  if ((rc = use_static ? bufs_from_static(ctx, S, P, &B) : bufs_from_ctx(ctx, S, P, &B))) return rc;
+  if ((rc = use_static ? bufs_from_static(ctx, s, P, &B) : bufs_from_ctx(ctx, s, P, &B))) return rc;
+  const bool split = pass_split(ctx, s);
   const size_t ncount = kCountWords;
   uint32_t* counts = B.counts;
   uint32_t* phong_counts = counts + CFTRT_MAX_LEVELS + 1;
@@ -1233,17 +1299,18 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
   HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)counts, (int)P, 1, st_));   // counts[0] = P (no host staging buffer)
 
   QueueDev q[2] = {B.q[0], B.q[1]};
-  HitDev hA = B.hA, hB = B.hB;
+  const LookRecs hA = B.hA;
+  const HitDev hB = B.hB;
   PhongQueueDev pq = B.pq;
   Rad3* rad = B.rad;
 
   const int tiled = (C.width % 32u == 0 && C.height % 8u == 0 && npix == C.width * C.height && P % npix == 0 && pid_base % npix == 0) ? 1 : 0;
   const GenArgs gen{C, jitter, tiled};
-  if (tiled && ctx->tiles_active && !ctx->split && !use_static) {
+  if (tiled && ctx->tiles_active && !split && !use_static) {
     S.tile_off = (const uint32_t*)ctx->tile_off.p;
     S.tile_idx = (const uint32_t*)ctx->tile_idx.p;
   }
-  if (ctx->split) {   // the fused pipeline generates inside its level-0 launch
+  if (split) {   // the fused pipeline generates inside its level-0 launch
     if (tm.begin(CLS_GEN)) return fail(ctx, CFTRT_ERR_HIP, "hipEventCreate failed");
     hipLaunchKernelGGL(k_generate, dim3(grid_for(ctx, P, 16)), dim3(CFT_BLOCK), 0, st_, C, pid_base, P, k0, k1, jitter, tiled, q[0]);
   }
@@ -1251,17 +1318,19 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
   uint32_t ub = P;   // upper bound on the live rays of the current level (a ray spawns at most one ray)
   uint32_t levels_run = 0;
   uint32_t in_D = 0;   // segment stride of the current level's input queue (0: dense)
-  // Motion key of the lights' `looked` scan: the reference scans once per light that looks (SkyLight, LightShape),
-  // keyed here by that light's index in world.lights (Point/Parallel lights never scan, light.rs:17-19).  With
-  // several such lights the scans share the first one's key (known deviations).
+  // Motion key of a light's `looked` scan: the reference scans once per light that looks (SkyLight, LightShape),
+  // keyed here by that light's index in world.lights (Point/Parallel lights never scan, light.rs:17-19).  A moving
+  // scene with several such lights (s->multi_look) runs one scan per light, through the split pipeline.
   uint32_t looked_role = 0;
+  std::vector<uint32_t> look_roles;
   for (size_t i = 0; i < s->lights.size(); ++i)
-    if (s->lights[i].kind == CFTRT_LIGHT_SKY || s->lights[i].kind == CFTRT_LIGHT_SHAPE) { looked_role = (uint32_t)i; break; }
+    if (s->lights[i].kind == CFTRT_LIGHT_SKY || s->lights[i].kind == CFTRT_LIGHT_SHAPE) look_roles.push_back((uint32_t)i);
+  if (!look_roles.empty()) looked_role = look_roles[0];
   for (uint32_t level = 0; level < max_depth; ++level) {
     const uint32_t grid = grid_for(ctx, ub, 8);
     int in = level & 1, outq = in ^ 1;
     const uint32_t nl = (uint32_t)S.n_lights;
-    if (!ctx->split) {
+    if (!split) {
       if (tm.begin(CLS_ISECT)) return fail(ctx, CFTRT_ERR_HIP, "hipEventCreate failed");   // booked as the intersect class (ms_shade stays 0)
       // big levels append through CFT_SHARDS counters (one counter takes ~88 appends per microsecond)
       uint32_t out_D = (ctx->shards && ub >= (1u << 22) && level + 1 < max_depth) ? 1u : 0u;
@@ -1270,7 +1339,13 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
       in_D = out_D;
     } else {
       tm.begin(CLS_ISECT);
-      launch_intersect(ctx, S, q[in], counts, level, pid_base, k0, k1, two_scans, two_scans ? looked_role : nl, nl, hA, hB, xstats, ub);
+      if (s->multi_look) {   // one scan per looking light, then trace's own: each with its own motion times
+        for (int k = 0; k < hA.n; ++k)
+          launch_intersect(ctx, S, q[in], counts, level, pid_base, k0, k1, false, look_roles[(size_t)k], look_roles[(size_t)k], hA.r[k], hA.r[k], xstats, ub);
+        launch_intersect(ctx, S, q[in], counts, level, pid_base, k0, k1, false, nl, nl, hB, hB, xstats, ub);
+      } else {
+        launch_intersect(ctx, S, q[in], counts, level, pid_base, k0, k1, two_scans, two_scans ? looked_role : nl, nl, hA.r[0], hB, xstats, ub);
+      }
       tm.begin(CLS_SHADE);
       hipLaunchKernelGGL(k_shade, dim3(grid), dim3(CFT_BLOCK), 0, st_, S, q[in], hA, hB, counts, level, max_depth,
                          pid_base, k0, k1, q[outq], rad, pq, phong_counts);
@@ -1295,7 +1370,7 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
       }
       if (ctx->host_counts[0] == 0) break;
       ub = ctx->host_counts[0];
-      if (!ctx->split && !phong && ctx->finish && !ctx->variant && ub < ctx->finish_below) {
+      if (!split && !phong && ctx->finish && !ctx->variant && ub < ctx->finish_below) {
         // few rays left: every remaining level in ONE launch, path by path (k_trace_finish); one lane per live ray,
         // at most what the chip holds at once (lanes refill from the queue)
         if (tm.begin(CLS_ISECT)) return fail(ctx, CFTRT_ERR_HIP, "hipEventCreate failed");
@@ -1375,7 +1450,7 @@ static int render_impl(cftrt_scene* s, const cftrt_camera* cam, uint32_t width, 
   if (npix > (1ull << 31)) return fail(ctx, CFTRT_ERR_LIMIT, "image beyond 2^31 pixels");
   // a pass renders whole samples of the image; the static workspace keeps 4 KiB + 256 B per buffer for its carving
   const uint64_t limit = use_static ? (uint64_t)CFTRT_STATIC_SCRATCH_BYTES - kStaticHeader - 16 * 256 : ctx->ws_limit;
-  uint64_t spp_pass = limit / (bytes_per_path(ctx, s->dev) * npix);
+  uint64_t spp_pass = limit / (bytes_per_path(ctx, s) * npix);
   spp_pass = std::min<uint64_t>(spp_pass, 0xFFFFFF00ull / npix);
   if (spp_pass == 0)
     return fail(ctx, CFTRT_ERR_LIMIT, use_static ? "one sample per pixel does not fit the static workspace (CFTRT_STATIC_SCRATCH_BYTES)"
@@ -1452,7 +1527,7 @@ int cftrt_render(cftrt_scene* s, const cftrt_camera* cam, uint32_t width, uint32
 // ------------------------------------------------------------------ multi-GPU: the one exchange step
 int cftrt_comm_unique_id(unsigned char* id128) {
   if (!id128) return CFTRT_ERR_INVALID;
-  RcclApi* R = rccl_api(&g_create_error);
+  const RcclApi* R = rccl_api(&g_create_error);
   if (!R) return CFTRT_ERR_HIP;
   RcclApi::UniqueId id;
   const int rc = R->GetUniqueId(&id);
@@ -1465,7 +1540,7 @@ int cftrt_comm_init(cftrt_ctx* ctx, int nranks, int rank, const unsigned char* i
   if (!ctx) return CFTRT_ERR_INVALID;
   if (!id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, CFTRT_ERR_INVALID, "comm_init: bad rank, size or id");
   if (ctx->comm) return fail(ctx, CFTRT_ERR_STATE, "comm_init: this ctx already has a communicator");
-  RcclApi* R = rccl_api(&ctx->err);
+  const RcclApi* R = rccl_api(&ctx->err);
   if (!R) return CFTRT_ERR_HIP;
   DEVICE_GUARD(ctx);
   RcclApi::UniqueId id;
@@ -1481,7 +1556,7 @@ int cftrt_reduce(cftrt_ctx* ctx, void* accum_device, uint64_t n_floats, int root
   if (!ctx->comm) return fail(ctx, CFTRT_ERR_STATE, "reduce: no communicator (cftrt_comm_init)");
   if (!accum_device && n_floats) return fail(ctx, CFTRT_ERR_INVALID, "reduce: null buffer");
   if (root < 0 || root >= ctx->comm_ranks) return fail(ctx, CFTRT_ERR_INVALID, "reduce: root out of range");
-  RcclApi* R = rccl_api(&ctx->err);
+  const RcclApi* R = rccl_api(&ctx->err);
   if (!R) return CFTRT_ERR_HIP;
   DEVICE_GUARD(ctx);
   // in place: every rank's buffer is summed into root's (ncclFloat32 = 7, ncclSum = 0), on the ctx's stream, so it is
@@ -1495,7 +1570,7 @@ int cftrt_reduce(cftrt_ctx* ctx, void* accum_device, uint64_t n_floats, int root
 int cftrt_comm_destroy(cftrt_ctx* ctx) {
   if (!ctx) return CFTRT_ERR_INVALID;
   if (!ctx->comm) return CFTRT_OK;
-  RcclApi* R = rccl_api(&ctx->err);
+  const RcclApi* R = rccl_api(&ctx->err);
   if (R) { DeviceGuard guard(ctx->device); (void)R->CommDestroy(ctx->comm); }
   ctx->comm = nullptr;
   ctx->comm_ranks = 0;
@@ -1565,6 +1640,94 @@ int cftrt_intersect(cftrt_scene* s, const float* rays, uint64_t n, uint64_t seed
   return CFTRT_OK;
 }
 
+int cftrt_level_hits(cftrt_scene* s, const cftrt_camera* cam, uint32_t width, uint32_t height, const float* rays, uint64_t n,
+                     uint64_t seed, uint64_t pid0, uint32_t level, int32_t* out_id, double* out_t, int32_t* out_scans) {
+  if (!s) return CFTRT_ERR_INVALID;
+  cftrt_ctx* ctx = s->ctx;
+  if (!s->committed) return fail(ctx, CFTRT_ERR_STATE, "scene not committed");
+  if (n && (!out_id || !out_t)) return fail(ctx, CFTRT_ERR_INVALID, "level_hits: null output");
+  if (n > (1ull << 26)) return fail(ctx, CFTRT_ERR_LIMIT, "level_hits hook: more than 2^26 rays");
+  if (level >= CFTRT_MAX_LEVELS) return fail(ctx, CFTRT_ERR_LIMIT, "level beyond CFTRT_MAX_LEVELS (256)");
+  if (pass_split(ctx, s)) return fail(ctx, CFTRT_ERR_STATE, "level_hits: the hook runs the fused level kernel (split pipeline in use)");
+  const bool gen_mode = rays == nullptr;
+  CamDev C;
+  memset(&C, 0, sizeof C);
+  const uint64_t npix = (uint64_t)width * height;
+  if (gen_mode) {
+    if (int rc = make_cam(ctx, cam, width, height, &C)) return rc;
+    if (level != 0 || npix == 0 || npix > 0xFFFFFFFFull || pid0 % npix || n % npix)
+      return fail(ctx, CFTRT_ERR_INVALID, "level_hits without rays: level 0 and whole samples of the image only");
+  }
+  SceneDev S = s->dev;
+  const bool two_scans = S.any_motion && S.n_lights > 0;
+  if (out_scans) *out_scans = two_scans ? 2 : 1;
+  if (n == 0) return CFTRT_OK;
+  DEVICE_GUARD(ctx);
+  S.wave_cull = ctx->wave_cull;
+  S.grid_mode = S.gnx ? ctx->grid : 0;
+  if (S.grid_mode == 1 && S.n_sphF + S.n_msph + S.n_triF > 4096) S.grid_mode = 2;   // as run_pass does
+  int rc;
+  if (gen_mode && (rc = build_tile_lists(s, C, cam))) return rc;
+  PassBufs B;
+  if ((rc = bufs_from_ctx(ctx, s, (uint32_t)n, &B))) return rc;
+  const int NS = two_scans ? 2 : 1;
+  const size_t off_prim = (size_t)n * NS * 8;
+  if ((rc = ensure(ctx, ctx->misc, off_prim + (size_t)n * NS * 4))) return rc;
+  double* dbg_t = (double*)ctx->misc.p;
+  int32_t* dbg_prim = (int32_t*)((char*)ctx->misc.p + off_prim);
+  hipStream_t st_ = ctx->stream;
+  uint32_t* counts = B.counts;
+  HIP_TRY(ctx, hipMemsetAsync(counts, 0, kCountWords * 4, st_));
+  HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)(counts + level), (int)n, 1, st_));
+  HIP_TRY(ctx, hipMemsetAsync(dbg_prim, 0xFF, (size_t)n * NS * 4, st_));
+  if (!gen_mode) {   // the caller's rays as a dense input queue: throughput 1, local path id = index
+    std::vector<float4> a(n), b(n);
+    std::vector<float2> c(n);
+    for (uint64_t i = 0; i < n; ++i) {
+      const float* r = rays + 6 * i;
+      a[i] = make_float4(r[0], r[1], r[2], r[3]);
+      b[i] = make_float4(r[4], r[5], 1.f, 1.f);
+      uint32_t lp = (uint32_t)i;
+      float lpf;
+      memcpy(&lpf, &lp, 4);
+      c[i] = make_float2(1.f, lpf);
+    }
+    const QueueDev& q = B.q[level & 1];
+    HIP_TRY(ctx, hipMemcpyAsync(q.a, a.data(), n * 16, hipMemcpyHostToDevice, st_));
+    HIP_TRY(ctx, hipMemcpyAsync(q.b, b.data(), n * 16, hipMemcpyHostToDevice, st_));
+    HIP_TRY(ctx, hipMemcpyAsync(q.c, c.data(), n * 8, hipMemcpyHostToDevice, st_));
+    HIP_TRY(ctx, hipStreamSynchronize(st_));   // (the staging vectors die at the end of this block)
+  }
+  const int tiled = gen_mode && C.width % 32u == 0 && C.height % 8u == 0 ? 1 : 0;
+  const GenArgs gen{C, 1, tiled};
+  if (tiled && ctx->tiles_active) {
+    S.tile_off = (const uint32_t*)ctx->tile_off.p;
+    S.tile_idx = (const uint32_t*)ctx->tile_idx.p;
+  }
+  uint32_t looked_role = 0;
+  for (size_t i = 0; i < s->lights.size(); ++i)
+    if (s->lights[i].kind == CFTRT_LIGHT_SKY || s->lights[i].kind == CFTRT_LIGHT_SHAPE) { looked_role = (uint32_t)i; break; }
+  const uint32_t nl = (uint32_t)S.n_lights;
+  uint32_t out_D = 0;
+  // one launch of the level kernel exactly as a render call issues it at this level (instance by scene kind, rays per
+  // lane, wave cull, grid walk / tile lists); the level is the last one (max_depth = level + 1), so nothing is appended
+  launch_trace_level(ctx, S, B.q[level & 1], counts, level, level + 1, pid0, (uint32_t)seed, (uint32_t)(seed >> 32), two_scans,
+                     two_scans ? looked_role : nl, nl, B.q[(level & 1) ^ 1], B.rad, B.pq, counts + CFTRT_MAX_LEVELS + 1,
+                     counts + 2 * CFTRT_MAX_LEVELS + 2, (uint32_t)n, gen_mode ? &gen : nullptr, 0, &out_D, dbg_t, dbg_prim);
+  ctx->tiles_active = false;
+  std::vector<int32_t> prim((size_t)n * NS);
+  HIP_TRY(ctx, hipMemcpyAsync(out_t, dbg_t, (size_t)n * NS * 8, hipMemcpyDeviceToHost, st_));
+  HIP_TRY(ctx, hipMemcpyAsync(prim.data(), dbg_prim, (size_t)n * NS * 4, hipMemcpyDeviceToHost, st_));
+  HIP_TRY(ctx, hipStreamSynchronize(st_));
+  HIP_TRY(ctx, hipGetLastError());
+  const int32_t ns = (int32_t)s->sph_obj.size();
+  for (size_t i = 0; i < prim.size(); ++i) {
+    const int32_t g = prim[i];
+    out_id[i] = g < 0 ? -1 : (g < ns ? s->sph_obj[(size_t)g] : s->tri_obj[(size_t)(g - ns)]);
+  }
+  return CFTRT_OK;
+}
+
 int cftrt_trace_paths(cftrt_scene* s, const cftrt_camera* cam, uint32_t width, uint32_t height, uint64_t pid0, uint64_t n,
                       uint32_t max_depth, uint64_t seed, int jitter, float* out_rgb, cftrt_stats* stats) {
   if (!s) return CFTRT_ERR_INVALID;
@@ -1585,7 +1748,19 @@ int cftrt_trace_paths(cftrt_scene* s, const cftrt_camera* cam, uint32_t width, u
     if (stats) *stats = st;
     return CFTRT_OK;
   }
-  int rc = run_pass(s, C, pid0, (uint32_t)n, 1, (uint32_t)n, max_depth, seed, jitter, nullptr, &st, tm);
+  // Whole samples of the image run as the render calls run them: per-tile lists for the primary rays, the queue in
+  // 32x8-pixel tiles (when the size allows), 24-byte level-0 rays, slot-numbered survivors.  Anything else is one
+  // row-major pass over the n paths.
+  const uint64_t npix = (uint64_t)width * height;
+  const bool whole = npix <= 0xFFFFFFFFull && pid0 % npix == 0 && n % npix == 0;
+  int rc = CFTRT_OK;
+  if (whole) {
+    if ((rc = build_tile_lists(s, C, cam))) return rc;
+    rc = run_pass(s, C, pid0, (uint32_t)n, (uint32_t)(n / npix), (uint32_t)npix, max_depth, seed, jitter, nullptr, &st, tm);
+    ctx->tiles_active = false;
+  } else {
+    rc = run_pass(s, C, pid0, (uint32_t)n, 1, (uint32_t)n, max_depth, seed, jitter, nullptr, &st, tm);
+  }
   if (rc) return rc;
   std::vector<Rad3> rad(n);
   HIP_TRY(ctx, hipMemcpy(rad.data(), ctx->rad.p, n * 12, hipMemcpyDeviceToHost));

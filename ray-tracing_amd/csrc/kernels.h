@@ -155,15 +155,28 @@ __device__ __forceinline__ bool exact_prim(const SceneDev& S, int g, d3 o, d3 d,
   int ti = g - S.n_sph;
   const double* tp = S.triD + 9 * (size_t)ti;
   d3 p0 = ld3(tp), p1 = ld3(tp + 3), p2 = ld3(tp + 6);
+  d3 dl = d3{0., 0., 0.};
   if (S.any_motion) {
     d3 mv = ld3(S.triMvD + 3 * (size_t)ti);
     if (mv.x != 0. || mv.y != 0. || mv.z != 0.) {
       double tm = (double)motion_time(scan_word, (uint32_t)S.prim_obj[g]);
       d3 delta = mv * tm;
       p0 = p0 + delta; p1 = p1 + delta; p2 = p2 + delta;
+      dl = delta;
     }
   }
-  return exact_tri(o, d, p0, p1, p2, t_out);
+  bool hit = exact_tri(o, d, p0, p1, p2, t_out);
+  if (S.any_pairs && hit) {
+    // the second triangle of a Square::from_points: no hit where the first one is hit (tri0.or(tri1), object.rs:192);
+    // both belong to one object, so they move by the same delta
+    const int f = S.tri_first[ti];
+    if (f >= 0) {
+      const double* fp = S.triD + 9 * (size_t)f;
+      double t0;
+      if (exact_tri(o, d, ld3(fp) + dl, ld3(fp + 3) + dl, ld3(fp + 6) + dl, &t0)) hit = false;
+    }
+  }
+  return hit;
 }
 
 // Ray::hit in f64 over every primitive (the fallback when the f32 cull cannot decide); lowest object index wins
@@ -1163,18 +1176,24 @@ __device__ __forceinline__ Winner ray_epilogue_w(const SceneDev& S, float ox, fl
   r.t = pre.t; r.g = pre.g; r.obj = -1; r.mat = 0; r.geom = false;
   r.c = d3{0., 0., 0.}; r.rad = 0.;
   auto obj_of = [&](const Winner& w) { return w.obj >= 0 ? w.obj : S.prim_obj[w.g]; };   // (only on exact ties)
+  // Exact ties go to the lower object index and, inside one object (two faces of a Cube, the two triangles of a Square),
+  // to the lower prim id - the first minimum of the reference's scans (ray.rs:23-27, object.rs:192,246-253) and the
+  // order of exact_scan_all_wave.  A total order: the result does not depend on which of two tied candidates the f32
+  // scan happened to rank first (the per-tile lists are filled through atomics, in no fixed order).
+  auto wins_tie = [&](const Winner& w, const Winner& cur) {
+    const int a = w.obj, b = obj_of(cur);
+    return a < b || (a == b && w.g < cur.g);
+  };
   if (c.i1 >= 0) {
     Winner w;
     double t;
-    if (exact_list_prim(S, c.i1, o, d, word, &t, &w) &&
-        (r.g < 0 || t < r.t || (t == r.t && w.obj < obj_of(r)))) { r = w; r.t = t; }
+    if (exact_list_prim(S, c.i1, o, d, word, &t, &w) && (r.g < 0 || t < r.t || (t == r.t && wins_tie(w, r)))) { r = w; r.t = t; }
   }
   const bool second = c.i2 >= 0 && (double)c.lo2 <= r.t;
   if (second) {
     Winner w;
     double t;
-    if (exact_list_prim(S, c.i2, o, d, word, &t, &w) &&
-        (r.g < 0 || t < r.t || (t == r.t && w.obj < obj_of(r)))) { r = w; r.t = t; }
+    if (exact_list_prim(S, c.i2, o, d, word, &t, &w) && (r.g < 0 || t < r.t || (t == r.t && wins_tie(w, r)))) { r = w; r.t = t; }
   }
   const bool rescan = c.lo3 < __builtin_inff() && (double)c.lo3 <= r.t;   // lo3 = +inf unless a third candidate exists
   // the caller runs the rescan where the whole wave is convergent (lanes without a ray help too)
@@ -1781,7 +1800,17 @@ __device__ __forceinline__ bool light_shape_hit(const SceneDev& S, const LightDe
   for (int k = 0; k < L.tri_count; ++k) {
     const double* tp = S.ltriD + 9 * (size_t)(L.tri_begin + k);
     double t;
-    if (exact_tri(o, d, ld3(tp), ld3(tp + 3), ld3(tp + 6), &t) && t < bt) { bt = t; any = true; }
+    if (exact_tri(o, d, ld3(tp), ld3(tp + 3), ld3(tp + 6), &t)) {
+      if (S.any_pairs) {   // LightShape(Square::from_points): tri0.or(tri1), as in exact_prim
+        const int f = S.ltri_first[L.tri_begin + k];
+        if (f >= 0) {
+          const double* fp = S.ltriD + 9 * (size_t)f;
+          double t0;
+          if (exact_tri(o, d, ld3(fp), ld3(fp + 3), ld3(fp + 6), &t0)) continue;
+        }
+      }
+      if (t < bt) { bt = t; any = true; }
+    }
   }
   *t_out = bt;
   return any;
@@ -1807,8 +1836,6 @@ __device__ __forceinline__ bool shade_one(const SceneDev& S, const H& hit, f3 po
   f3 thr = *thr_io;
   f3 npos = mk3(0, 0, 0), ndir = mk3(0, 0, 0);
   bool alive = false;
-  const float4 A0 = hit.A0();
-  const int primA = __float_as_int(A0.y);
   // the material row is two dependent loads away from the prim id: start them before the lights and HitInfo::new
   const float4 B0 = hit.B0();
   const int prim = __float_as_int(B0.y);
@@ -1817,6 +1844,7 @@ __device__ __forceinline__ bool shade_one(const SceneDev& S, const H& hit, f3 po
   // ---- lights: LightSource::looked (object.rs:333-341)
   bool see = false;
   f3 col = mk3(0, 0, 0);
+  int kl = 0;   // ordinal of the light among those that look: picks its scan's record where each light has its own
   for (int l = 0; l < S.n_lights; ++l) {
     LightDev L;   // wave-uniform row: scalar loads
     {
@@ -1828,12 +1856,16 @@ __device__ __forceinline__ bool shade_one(const SceneDev& S, const H& hit, f3 po
       __builtin_memcpy(&L, w, sizeof L);
     }
     if (L.kind == 0) {                       // SkyLight::looked, light.rs:184-190
+      const int primA = __float_as_int(hit.A0(kl).y);
       if (primA < 0) { see = true; col = col + sky_color_from(dir); }
+      ++kl;
     } else if (L.kind == 1) {                // LightShape::looked, light.rs:233-242
       double tl;
       if (light_shape_hit(S, L, pos, dir, &tl)) {
-        if (primA < 0 || tl < hit.tA()) { see = true; col = col + mk3(L.r, L.g, L.b); }   // f64 against f64 (light.rs:236)
+        const int primA = __float_as_int(hit.A0(kl).y);
+        if (primA < 0 || tl < hit.tA(kl)) { see = true; col = col + mk3(L.r, L.g, L.b); }   // f64 against f64 (light.rs:236)
       }
+      ++kl;
     }
   }
   if (see) {
@@ -1898,11 +1930,12 @@ __device__ __forceinline__ bool shade_one(const SceneDev& S, const H& hit, f3 po
 }
 
 struct HitFromRecords {   // the split pipeline: hit records written by k_intersect, loaded on demand
-  HitDev A, B;
+  const LookRecs& A;   // (the kernel's own argument: a wave-uniform k indexes it through scalar loads)
+  HitDev B;
   uint32_t i;
-  __device__ __forceinline__ double tA() const { return A.t[i]; }
+  __device__ __forceinline__ double tA(int k) const { return A.r[k < A.n ? k : 0].t[i]; }
   __device__ __forceinline__ int mat(const SceneDev& S, int prim) const { return prim >= 0 ? S.prim_mat[prim] : 0; }
-  __device__ __forceinline__ float4 A0() const { return A.h0[i]; }
+  __device__ __forceinline__ float4 A0(int k) const { return A.r[k < A.n ? k : 0].h0[i]; }
   __device__ __forceinline__ float4 B0() const { return B.h0[i]; }
   __device__ __forceinline__ float4 B1() const { return B.h1[i]; }
 };
@@ -1910,16 +1943,16 @@ struct HitInRegisters {   // the fused pipeline
   float4 a0, b0, b1;
   double ta;   // exact distance of the lights' `looked` scan
   int mat_id;  // material row of trace's own hit (0 on a miss)
-  __device__ __forceinline__ double tA() const { return ta; }
-  __device__ __forceinline__ int mat(const SceneDev&, int) const { return mat_id; }
-  __device__ __forceinline__ float4 A0() const { return a0; }
+  __device__ __forceinline__ double tA(int) const { return ta; }   // (one `looked` scan serves every light: the host
+  __device__ __forceinline__ int mat(const SceneDev&, int) const { return mat_id; }   // sends moving scenes with several looking lights through the split pipeline)
+  __device__ __forceinline__ float4 A0(int) const { return a0; }
   __device__ __forceinline__ float4 B0() const { return b0; }
   __device__ __forceinline__ float4 B1() const { return b1; }
 };
 
 // SPLIT pipeline, shade stage: one lane = one (ray, hit) record of this level.  hitA = the lights' `looked`
 // scan, hitB = trace's own scan (the same buffers for a static scene).
-__global__ __launch_bounds__(CFT_BLOCK) void k_shade(SceneDev S, QueueDev qin, HitDev hitA, HitDev hitB,
+__global__ __launch_bounds__(CFT_BLOCK) void k_shade(SceneDev S, QueueDev qin, LookRecs hitA, HitDev hitB,
                                                      uint32_t* counts, uint32_t level, uint32_t max_depth,
                                                      uint64_t pid_base, uint32_t k0, uint32_t k1, QueueDev qout,
                                                      Rad3* radiance, PhongQueueDev pq, uint32_t* phong_counts) {
@@ -2080,6 +2113,10 @@ struct LevelArgs {
   uint32_t* stats;
   GenArgs gen;
   uint32_t in_D, out_k, out_D;
+  // parity hook (cftrt_level_hits; null in every render call): the winner of each scan of each ray as this kernel found
+  // it, by local path id - exact distance dbg_t[NS lp + k], global prim id dbg_prim[NS lp + k] (-1: miss)
+  double* dbg_t;
+  int32_t* dbg_prim;
 };
 template <typename T>
 __device__ __forceinline__ const T& kernel_args() {   // (the kernel's one parameter is a T: offset 0 of the segment)
@@ -2235,9 +2272,12 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(LevelArgs) {
         HitInRegisters hit;
         isect_hit<NS>(S, live, r, 0, a.x, a.y, a.z, a.w, b.x, b.y, park, A.stats, &hit.a0, &hit.b1, &hit.ta, &hit.mat_id);
         hit.b0 = hit.a0;
-        if (NS == 2) {
-          double tb;
-          isect_hit<NS>(S, live, r, 1, a.x, a.y, a.z, a.w, b.x, b.y, park, A.stats, &hit.b0, &hit.b1, &tb, &hit.mat_id);
+        double tb = hit.ta;
+        if (NS == 2) isect_hit<NS>(S, live, r, 1, a.x, a.y, a.z, a.w, b.x, b.y, park, A.stats, &hit.b0, &hit.b1, &tb, &hit.mat_id);
+        if (A.dbg_t != nullptr && live) {   // (wave-uniform pointer test; never taken in a render call)
+          const size_t w0 = (size_t)NS * __float_as_uint(c.y);
+          A.dbg_t[w0] = hit.ta; A.dbg_prim[w0] = __float_as_int(hit.a0.y);
+          if (NS == 2) { A.dbg_t[w0 + 1] = tb; A.dbg_prim[w0 + 1] = __float_as_int(hit.b0.y); }
         }
         CFT_STAMP(4);   // (diagnostic build: "park" = the exact evaluation and hit record of the slots; "epilogue" = shading)
         f3 thr = mk3(b.z, b.w, c.x), npos, ndir;
@@ -2305,7 +2345,7 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_tail(SceneDev S, QueueDe
                                                           uint32_t max_depth, uint64_t pid_base, uint32_t k0,
                                                           uint32_t k1, uint32_t role0, uint32_t role1, QueueDev qout,
                                                           Rad3* radiance, PhongQueueDev pq, uint32_t* phong_counts,
-                                                          uint32_t* stats) {
+                                                          uint32_t* stats, double* dbg_t, int32_t* dbg_prim) {
   __shared__ float park[ParkLayout<NS>::WORDS * R][CFT_BLOCK];
   const uint32_t n = counts[level];
   const uint32_t lane = threadIdx.x & 63u;
@@ -2364,9 +2404,12 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_tail(SceneDev S, QueueDe
       HitInRegisters hit;
       isect_hit<NS>(S, live, r, 0, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.a0, &hit.b1, &hit.ta, &hit.mat_id);
       hit.b0 = hit.a0;
-      if (NS == 2) {
-        double tb;
-        isect_hit<NS>(S, live, r, 1, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.b0, &hit.b1, &tb, &hit.mat_id);
+      double tb = hit.ta;
+      if (NS == 2) isect_hit<NS>(S, live, r, 1, a.x, a.y, a.z, a.w, b.x, b.y, park, stats, &hit.b0, &hit.b1, &tb, &hit.mat_id);
+      if (dbg_t != nullptr && live) {   // (parity hook, see LevelArgs)
+        const size_t w0 = (size_t)NS * __float_as_uint(c.y);
+        dbg_t[w0] = hit.ta; dbg_prim[w0] = __float_as_int(hit.a0.y);
+        if (NS == 2) { dbg_t[w0 + 1] = tb; dbg_prim[w0 + 1] = __float_as_int(hit.b0.y); }
       }
       f3 thr = mk3(b.z, b.w, c.x), npos, ndir;
       const bool alive = live && shade_one(S, hit, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), &thr, __float_as_uint(c.y), level,

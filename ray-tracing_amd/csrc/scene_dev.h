@@ -59,6 +59,12 @@ struct SceneDev {
   const double* triD;     // n_tri x 9: p0, p1, p2
   const double* triMvD;   // n_tri x 3
   int n_tri;
+  // Square::from_points (object.rs:169-174): its hit is tri0.or(tri1) (object.rs:192) - the second triangle counts only
+  // where the first is not hit, whatever the distances.  tri_first[i] = the triangle (index into triD, same object)
+  // that shadows triangle i this way, -1 for every other triangle; likewise ltri_first for the light shapes' triangles.
+  const int* tri_first;
+  const int* ltri_first;
+  int any_pairs;          // some entry of tri_first / ltri_first is >= 0
   // ---- the listed primitives again, in LIST order (index = what the f32 scan hands over), so that the exact evaluation of
   // a candidate starts with one round of loads instead of list index -> prim id -> data -> material id:
   const double* lsD;      // static list spheres, 4 each: cx, cy, cz, r
@@ -106,4 +112,13 @@ struct HitDev {
   float4* h0;  // t (f32-rounded), prim (int bits; -1 = miss), px, py
   float4* h1;  // pz, nx, ny, nz   (geometric unit normal before HitInfo::new's flip)
   double* t;   // the exact f64 distance (+inf on a miss): LightShape::looked compares distances in f64 (light.rs:236)
+};
+// The records of the lights' `looked` scans (split pipeline).  One record set serves every light of a static scene (the
+// scans are identical) and the one looked-capable light of a moving scene; a MOVING scene with several looked-capable
+// lights (SkyLight, LightShape) holds one set per such light, in the lights' order: the reference scans the world once
+// per light that looks, each scan with its own motion times (object.rs:333-338, light.rs:184-190,233-242).
+#define CFT_MAX_LOOK 8
+struct LookRecs {
+  HitDev r[CFT_MAX_LOOK];
+  int n;
 };

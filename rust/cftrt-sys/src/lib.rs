@@ -141,6 +141,13 @@ extern "C" {
         ltri_p2: *const f64,
         n_ltri: i64,
     ) -> c_int;
+    pub fn cftrt_scene_set_triangle_pairs(
+        scene: *mut cftrt_scene,
+        tri_first: *const i32,
+        n_tri: i64,
+        ltri_first: *const i32,
+        n_ltri: i64,
+    ) -> c_int;
     pub fn cftrt_scene_set_precise_radius(scene: *mut cftrt_scene, radius: f64) -> c_int;
     pub fn cftrt_scene_commit(scene: *mut cftrt_scene) -> c_int;
     // ---- the hot path
@@ -210,6 +217,20 @@ extern "C" {
         out_normal: *mut f32,
         out_point: *mut f32,
         out_outward: *mut i32,
+    ) -> c_int;
+    pub fn cftrt_level_hits(
+        scene: *mut cftrt_scene,
+        cam: *const cftrt_camera,
+        width: u32,
+        height: u32,
+        rays: *const f32,
+        n: u64,
+        seed: u64,
+        pid0: u64,
+        level: u32,
+        out_id: *mut i32,
+        out_t: *mut f64,
+        out_scans: *mut i32,
     ) -> c_int;
     pub fn cftrt_trace_paths(
         scene: *mut cftrt_scene,

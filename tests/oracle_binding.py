@@ -34,6 +34,8 @@ def lib():
         L.orc_add_triangle.argtypes = [C.c_void_p, _D, _D, _D, C.c_int, _D]
         L.orc_add_square.argtypes = [C.c_void_p, _D, _D, _D, C.c_double, C.c_int, _D]
         L.orc_add_cube.argtypes = [C.c_void_p, _D, _D, _D, C.c_double, C.c_int, _D]
+        L.orc_add_square_points.argtypes = [C.c_void_p, _D, _D, _D, _D, C.c_int, _D]
+        L.orc_add_light_square_points.argtypes = [C.c_void_p, _D, _D, _D, _D]
         L.orc_add_sky.argtypes = [C.c_void_p]
         L.orc_add_point_light.argtypes = [C.c_void_p, _D, _D]
         L.orc_add_parallel_light.argtypes = [C.c_void_p, _D, _D]
@@ -116,8 +118,10 @@ class OracleWorld:
             elif isinstance(s, A.Cube):
                 L.orc_add_cube(self.h, d3(s.center), d3(s.x), d3(s.y), s.len, mid, mv)
             elif isinstance(s, A.Square):
-                if s._ctor is None:
-                    raise TypeError("Square.from_points has no oracle constructor")
+                if s._ctor is None:   # Square::from_points (object.rs:169-174)
+                    q = s._points
+                    L.orc_add_square_points(self.h, d3(q[0]), d3(q[1]), d3(q[2]), d3(q[3]), mid, mv)
+                    continue
                 a = s._ctor
                 L.orc_add_square(self.h, d3(a[0]), d3(a[1]), d3(a[2]), a[3], mid, mv)
             else:
@@ -137,6 +141,9 @@ class OracleWorld:
                     L.orc_add_light_shape(self.h, 1, d3(s.p0), d3(s.p1), d3(s.p2), 0.0)
                 elif isinstance(s, A.Cube):
                     L.orc_add_light_shape(self.h, 3, d3(s.center), d3(s.x), d3(s.y), s.len)
+                elif s._ctor is None:
+                    q = s._points
+                    L.orc_add_light_square_points(self.h, d3(q[0]), d3(q[1]), d3(q[2]), d3(q[3]))
                 else:
                     a = s._ctor
                     L.orc_add_light_shape(self.h, 2, d3(a[0]), d3(a[1]), d3(a[2]), a[3])

@@ -267,6 +267,230 @@ def test_moving_scene_with_sky_as_second_light(rt, orc):
     assert abs(int(st.rays) - orays) <= 0.002 * orays
 
 
+# ------------------------------------------------------------------ the production level kernel, hit by hit
+def _check_level_hits(world, ow, rays, level, seed=SEED, pid0=0, nthreads=16, **kw):
+    """cftrt_level_hits (one launch of the fused level kernel as a render call issues it) against the oracle's linear
+    scan: object ids equal and distances equal BIT FOR BIT, for every scan of every ray."""
+    ids, t = world.level_hits(rays=rays, seed=seed, pid0=pid0, level=level, **kw)
+    nl = len(world.lights)
+    look = [i for i, l in enumerate(world.lights) if l.kind in (0, 1)]
+    roles = [look[0], nl] if ids.shape[1] == 2 else [nl]          # run_pass's motion keys
+    for k, role in enumerate(roles):
+        oid, ot = ow.hit(rays.astype(np.float64), seed=seed, pid0=pid0, level=level, role=role, nthreads=nthreads)[:2]
+        assert np.array_equal(ids[:, k], oid), f"scan {k}: {(ids[:, k] != oid).sum()} object ids differ"
+        assert np.array_equal(t[:, k], ot), f"scan {k}: {(t[:, k] != ot).sum()} distances differ"
+    return int((ids[:, -1] >= 0).sum())
+
+
+def _incoherent_rays(rng, n, lo, hi, zlo, zhi):
+    pos = np.c_[rng.uniform(lo, hi, n), rng.uniform(lo, hi, n), rng.uniform(zlo, zhi, n)]
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    rays = np.c_[pos, d].astype(np.float32)
+    dn = np.linalg.norm(rays[:, 3:].astype(np.float64), axis=1, keepdims=True)
+    rays[:, 3:] = (rays[:, 3:] / dn).astype(np.float32)
+    return rays
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+def test_level_kernel_hits_s500(rt, orc, variant):
+    """k_trace_level<R, 1, ..> on S500 with R = 1..4 rays per lane (0: the default choice, which below 2^17 rays is
+    the tail kernel): bounce-level launches walk the grid behind the in-wave sort (level 1), level-0 launches on
+    caller rays take the cone cull (wave cull on) or the plain lists (off), grid mode 2 walks at level 0 too."""
+    world, cam = rt.scenes.s500()
+    ow = orc.OracleWorld(world)
+    dev = rt.default_device()
+    rng = np.random.default_rng(50 + variant)
+    inc = _incoherent_rays(rng, 150000, -12, 12, 0.0005, 2.5)
+    prim = dev.generate(cam, 480, 270, 0, 480 * 270, SEED, True)
+    dev.set_variant(variant)
+    try:
+        assert _check_level_hits(world, ow, inc, level=1) > 0.3 * len(inc)
+        assert _check_level_hits(world, ow, prim, level=0) > 0.5 * len(prim)
+        assert _check_level_hits(world, ow, inc, level=0) > 0.3 * len(inc)
+        dev.set_wave_cull(False)
+        _check_level_hits(world, ow, prim, level=0)
+        dev.set_wave_cull(True)
+        dev.set_grid(2)
+        _check_level_hits(world, ow, prim, level=0)
+        dev.set_grid(0)
+        _check_level_hits(world, ow, inc, level=3)
+    finally:
+        dev.set_variant(0); dev.set_wave_cull(True); dev.set_grid(1)
+
+
+def test_level_kernel_hits_generated_primaries(rt, orc):
+    """Level 0 as the render calls run it: the launch generates its own rays in 32x8-pixel tiles and scans per-tile
+    lists (S500, S20k) - hits by path id against the oracle on the rays cftrt_generate returns for the same ids."""
+    dev = rt.default_device()
+    for name, W, H, spp in (("s500", 96, 56, 2), ("s20k", 160, 96, 1), ("scene_rs", 96, 56, 2)):
+        world, cam = getattr(rt.scenes, name)()
+        ow = orc.OracleWorld(world)
+        n = W * H * spp
+        rays = dev.generate(cam, W, H, 0, n, SEED, True)
+        nl = len(world.lights)
+        for variant in (0, 4, 2, 1, 3):
+            dev.set_variant(variant)
+            try:
+                ids, t = world.level_hits(camera=cam, width=W, height=H, n=n, seed=SEED, pid0=0, level=0)
+            finally:
+                dev.set_variant(0)
+            roles = [0, nl] if ids.shape[1] == 2 else [nl]
+            for k, role in enumerate(roles):
+                oid, ot = ow.hit(rays.astype(np.float64), seed=SEED, pid0=0, level=0, role=role, nthreads=16)[:2]
+                assert np.array_equal(ids[:, k], oid), (name, variant, k)
+                assert np.array_equal(t[:, k], ot), (name, variant, k)
+
+
+def test_level_kernel_hits_adversarial_moving_s20k(rt, orc):
+    """The same direct check on the hard sets: the adversarial-tie scene (triangles + spheres + a precise sphere, no
+    grid: the list instances), scene.rs with motion blur (two scans per ray in one pass, NS = 2, walk and lists), and
+    the full S20k scene (walk instances with triangles, 4 and 2 rays per lane)."""
+    dev = rt.default_device()
+    rng = np.random.default_rng(11)
+    w = rt.World.empty()
+    m = rt.LambertianModel(0.5)
+    base = rng.uniform(-2, 2, (40, 3))
+    for c in base:
+        w.add_obj(rt.Object(rt.Sphere(c, 0.5), m))
+        w.add_obj(rt.Object(rt.Sphere(c + rng.uniform(-1, 1, 3) * 1e-7, 0.5), m))
+        w.add_obj(rt.Object(rt.Sphere(c, 0.5), m))
+        w.add_obj(rt.Object(rt.Sphere(c + rng.uniform(-1, 1, 3) * 3e-6, 0.5 + 2e-6), m))
+    for k in range(20):
+        p = rng.uniform(-3, 3, (3, 3))
+        w.add_obj(rt.Object(rt.Triangle(*p), m))
+        w.add_obj(rt.Object(rt.Triangle(*p), m))
+        w.add_obj(rt.Object(rt.Triangle(*(p + rng.uniform(-1, 1, (3, 3)) * 1e-7)), m))
+    w.add_obj(rt.Object(rt.Sphere((0, 0, -30.0), 26.0), m))
+    w.add_obj(rt.Object(rt.Cube((0, 0, 0), (1, 0.2, 0), (0, 1, 0.1), 9.0), m))
+    n = 100000
+    pos = rng.uniform(-4, 4, (n, 3))
+    c = base[rng.integers(0, len(base), n)]
+    to_c = c - pos
+    perp = np.cross(to_c, rng.normal(size=(n, 3)))
+    perp /= np.linalg.norm(perp, axis=1)[:, None]
+    limb = c + perp * 0.5 * (1 + rng.uniform(-1, 1, (n, 1)) * 3e-7)
+    d = np.where((np.arange(n) % 3 == 0)[:, None], limb - pos, rng.normal(size=(n, 3)))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    rays = np.c_[pos, d].astype(np.float32)
+    dn = np.linalg.norm(rays[:, 3:].astype(np.float64), axis=1, keepdims=True)
+    rays[:, 3:] = (rays[:, 3:] / dn).astype(np.float32)
+    ow = orc.OracleWorld(w)
+    for variant in (4, 2, 0):
+        dev.set_variant(variant)
+        try:
+            assert _check_level_hits(w, ow, rays, level=2) > 0.9 * n
+        finally:
+            dev.set_variant(0)
+    # scene.rs, motion blur on: NS = 2
+    world, cam = rt.scenes.scene_rs()
+    ow = orc.OracleWorld(world)
+    prim = dev.generate(cam, 320, 200, 0, 320 * 200, SEED, True)
+    inc = _incoherent_rays(rng, 120000, -11, 11, 0.0005, 1.5)
+    for variant in (2, 1, 0):
+        dev.set_variant(variant)
+        try:
+            _check_level_hits(world, ow, prim, level=0, seed=99, pid0=1000)
+            _check_level_hits(world, ow, inc, level=3, seed=99, pid0=1000)
+        finally:
+            dev.set_variant(0)
+    # the full S20k scene: every level walks
+    world, cam = rt.scenes.s20k()
+    ow = orc.OracleWorld(world)
+    prim = dev.generate(cam, 224, 126, 0, 224 * 126, SEED, True)
+    inc = _incoherent_rays(rng, 30000, -11.5, 11.5, 0.0005, 1.2)
+    for variant in (4, 2):
+        dev.set_variant(variant)
+        try:
+            _check_level_hits(world, ow, inc, level=1)
+            _check_level_hits(world, ow, prim, level=0)
+        finally:
+            dev.set_variant(0)
+
+
+def test_square_from_points(rt, orc):
+    """Square::from_points (object.rs:169-174): tri0.or(tri1) - tri0 wins wherever it is hit, even behind tri1
+    (object.rs:192).  Non-planar and overlapping pairs, one of them moving, one as a LightShape; rays aimed at the
+    pairs: ids, distances (bit for bit) and normals against the oracle through the one-ray hook, the level kernel and
+    the whole loop."""
+    rng = np.random.default_rng(5)
+    A = rt
+    w = A.World.empty()
+    mats = [A.LambertianModel(0.8).with_color((0.8, 0.7, 0.6)), A.Metal(0.05, 0.9)]
+    quads = []
+    for i in range(24):
+        c = rng.uniform(-3, 3, 3)
+        p = [c + rng.uniform(-1, 1, 3) for _ in range(4)]        # four arbitrary corners: folded, overlapping pairs
+        quads.append(p)
+        o = A.Object(A.Square.from_points(*p), mats[i % 2])
+        if i % 6 == 0:
+            o = o.moved(tuple(rng.uniform(-0.3, 0.3, 3)))
+        w.add_obj(o)
+    for i in range(10):
+        w.add_obj(A.Object(A.Sphere(tuple(rng.uniform(-3, 3, 3)), 0.3), mats[i % 2]))
+    w.add_obj(A.Object(A.Square((0.0, 0.0, -4.0), (1.0, 0.0, 0.0), (0.0, 1.0, 0.0), 12.0), mats[0]))
+    lq = [np.array(q) for q in ((-1.0, -1.0, 4.0), (1.0, -1.0, 4.5), (-1.0, 1.0, 4.5), (0.2, 0.2, 3.2))]
+    w.add_light(A.LightShape(A.Square.from_points(*lq)))
+    ow = orc.OracleWorld(w)
+    n = 60000
+    k = rng.integers(0, len(quads), n)
+    Q = np.array(quads)[k]                                        # (n, 4, 3)
+    b = rng.dirichlet((1.0, 1.0, 1.0, 1.0), n)
+    target = (Q * b[:, :, None]).sum(axis=1)
+    org = rng.uniform(-5, 5, (n, 3))
+    d = target - org
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    rays = np.c_[org, d].astype(np.float32)
+    dn = np.linalg.norm(rays[:, 3:].astype(np.float64), axis=1, keepdims=True)
+    rays[:, 3:] = (rays[:, 3:] / dn).astype(np.float32)
+    for role in (0, 1):
+        assert _check_hits(w, ow, rays, seed=3, pid0=10, level=1, role=role) > 0.8 * n
+    # how often the rule matters: rays whose nearest triangle is a tri1 shadowed by its tri0
+    w2 = A.World.empty()
+    for p in quads:
+        w2.add_obj(A.Object(A.Triangle(*p[:3]), mats[0])); w2.add_obj(A.Object(A.Triangle(*p[1:]), mats[0]))
+    near = w2.intersect(rays)[0]
+    t_near = w2.intersect(rays)[1]
+    ids_pair, t_pair = w.intersect(rays, seed=3, pid0=10, level=1, role=1)[:2]
+    static = np.array([i % 6 != 0 for i in range(len(quads))])
+    first_is_tri1 = (near >= 0) & (near % 2 == 1) & static[np.clip(near // 2, 0, len(quads) - 1)]
+    # among the rays whose nearest triangle is a (static) pair's second one, many report a farther hit: the rule at work
+    assert (first_is_tri1 & (t_pair > t_near)).sum() > 300
+    dev = rt.default_device()
+    dev.set_variant(2)
+    try:
+        _check_level_hits(w, ow, rays, level=1, seed=3, pid0=10)
+    finally:
+        dev.set_variant(0)
+    cam = A.Camera.new((6.0, -5.0, 3.0), (0.0, 0.0, 0.0)).with_fov(50.0).with_aspect(1.5)
+    W, H, spp = 96, 64, 2
+    g, st = w.trace_paths(cam, W, H, 0, W * H * spp, 6, seed=8)
+    o, orays = ow.trace_paths(cam, W, H, 0, W * H * spp, 6, 8, nthreads=8)
+    assert (np.abs(g - o).max(axis=1) > 1e-3).mean() < 0.005
+    assert abs(int(st.rays) - orays) <= 0.002 * orays
+
+
+def test_moving_scene_with_two_looking_lights(rt, orc):
+    """World::trace asks every light `looked` in turn (object.rs:333-338) and each light that looks scans the world
+    itself, with fresh motion times per scan (light.rs:184-190,233-242, object.rs:42-55).  scene.rs with motion blur
+    and lights [LightShape, PointLight, SkyLight]: one scan per looking light (keyed 0 and 2) plus trace's own (3) -
+    per path against the oracle, which draws exactly those."""
+    world, cam = rt.scenes.scene_rs()
+    world.lights = [rt.LightShape(rt.Sphere((0.0, 0.0, 9.0), 3.0)), rt.PointLight((0.0, 0.0, 5.0)), rt.SkyLight()]
+    world._invalidate()
+    W, H, spp, depth = 96, 56, 4, 10
+    n = W * H * spp
+    g, st = world.trace_paths(cam, W, H, 0, n, depth, seed=11)
+    o, orays = orc.OracleWorld(world).trace_paths(cam, W, H, 0, n, depth, 11, nthreads=8)
+    differing = (np.abs(g - o).max(axis=1) > 1e-3).mean()
+    assert differing < 0.005, f"{differing:.4f} of the paths differ"
+    assert abs(int(st.rays) - orays) <= 0.002 * orays
+    assert np.abs(g.mean(0) - o.mean(0)).max() < 0.01 * o.mean()
+    # the image is the sum of those paths, whatever the pipeline switch says (such scenes always run split)
+    acc = world.render(cam.with_sample_rate(spp), W, H, depth, seed=11)
+    assert np.allclose(acc.reshape(-1, 3), g.reshape(spp, W * H, 3).sum(0), atol=1e-4)
+
+
 def test_known_answers(rt):
     """SURVEY §8c (1),(2) through the C ABI."""
     w = rt.World.empty()
@@ -352,12 +576,16 @@ def test_error_codes(rt):
 
 # ------------------------------------------------------------------ whole loop, same Philox keys
 @pytest.mark.parametrize("name,W,H,spp,depth", [("s500", 96, 54, 4, 50), ("cornell", 80, 60, 4, 10),
-                                                ("scene_rs", 80, 50, 4, 10)])
+                                                ("scene_rs", 80, 50, 4, 10), ("s500", 96, 56, 4, 50),
+                                                ("s20k", 96, 56, 2, 50), ("scene_rs", 96, 56, 4, 10), ("cornell", 96, 64, 4, 10)])
 def test_per_path_radiance(rt, orc, name, W, H, spp, depth):
-    world, cam = {"scene_rs": rt.scenes.scene_rs, "cornell": rt.scenes.cornell_rs, "s500": rt.scenes.s500}[name]()
+    """Sizes that are multiples of 32x8 run as the render calls do: queue in pixel tiles, per-tile lists for the primary
+    rays (S500, S20k, scene.rs), 24-byte level-0 rays, slot-numbered survivors; the others row-major."""
+    world, cam = {"scene_rs": rt.scenes.scene_rs, "cornell": rt.scenes.cornell_rs, "s500": rt.scenes.s500,
+                  "s20k": rt.scenes.s20k}[name]()
     n = W * H * spp
     g, st = world.trace_paths(cam, W, H, 0, n, depth, seed=11)
-    o, orays = orc.OracleWorld(world).trace_paths(cam, W, H, 0, n, depth, 11)
+    o, orays = orc.OracleWorld(world).trace_paths(cam, W, H, 0, n, depth, 11, nthreads=16)
     differing = (np.abs(g - o).max(axis=1) > 1e-3).mean()
     assert differing < 0.005, f"{differing:.4f} of the paths differ"
     assert abs(int(st.rays) - orays) <= 0.002 * orays
@@ -528,48 +756,6 @@ def test_wave_cull_is_exact(rt, name, W, H, spp, depth):
     assert list(sa.rays_per_level[: int(sa.levels)]) == list(sb.rays_per_level[: int(sb.levels)])
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4])
-def test_wave_cull_random_scenes(rt, seed):
-    """Random worlds (spheres from pebbles to boulders, a negative radius, moving spheres, triangles, squares, a cube,
-    mirrors and glass so that narrow bundles survive several bounces), camera inside the cloud: the image with the
-    wave-level cull must equal the image without it bit for bit."""
-    rng = np.random.default_rng(1000 + seed)
-    A = rt
-    world = A.World.empty()
-    mats = [A.LambertianModel(0.9).with_color((0.8, 0.6, 0.4)), A.Metal(0.0, 0.95), A.Metal(0.2, 0.9).with_color((0.9, 0.9, 1.0)),
-            A.Dielectric(1.5), A.Specular(0.9), A.Transparent(0.3, 1.3)]
-    world.add_obj(A.Object(A.Sphere((0.0, 0.0, -300.0), 300.0), mats[0]))
-    for i in range(150):
-        c = tuple(rng.uniform(-8, 8, 2)) + (float(rng.uniform(0.0, 3.0)),)
-        r = float(rng.choice([0.05, 0.2, 0.5, 1.5]) * rng.uniform(0.5, 1.5))
-        if i == 7:
-            r = -r
-        o = A.Object(A.Sphere(c, r), mats[int(rng.integers(len(mats)))])
-        if i % 5 == 0:
-            o = o.moved(tuple(rng.uniform(-0.5, 0.5, 3)))
-        world.add_obj(o)
-    for i in range(40):
-        p = rng.uniform(-8, 8, 3); p[2] = abs(p[2]) * 0.4
-        world.add_obj(A.Object(A.Triangle(tuple(p), tuple(p + rng.uniform(-1.5, 1.5, 3)), tuple(p + rng.uniform(-1.5, 1.5, 3))),
-                               mats[int(rng.integers(len(mats)))]))
-    world.add_obj(A.Object(A.Square((2.0, 1.0, 1.0), (1.0, 0.0, 0.0), (0.0, 0.6, 0.8), 1.2), mats[1]))
-    world.add_obj(A.Object(A.Cube((-3.0, 2.0, 0.6), (1.0, 0.2, 0.0), (-0.2, 1.0, 0.0), 1.0), mats[3]))
-    world.add_light(A.SkyLight())
-    cam = (A.Camera.new((6.0, -5.0, 1.5), (0.0, 0.0, 0.8)).with_fov(50.0).with_aspect(2.0).with_aperture(0.05)
-           .with_focus_dist(7.0).with_sample_rate(4))
-    W, H, depth = 256, 128, 12
-    dev = rt.default_device()
-    a, sa = world.render(cam, W, H, depth, seed=seed, return_stats=True)
-    dev.set_wave_cull(False)
-    try:
-        b, sb = world.render(cam, W, H, depth, seed=seed, return_stats=True)
-    finally:
-        dev.set_wave_cull(True)
-    assert np.array_equal(a, b)
-    assert list(sa.rays_per_level[: int(sa.levels)]) == list(sb.rays_per_level[: int(sb.levels)])
-    assert int(sa.rays) > 2 * W * H * 4          # paths do bounce
-
-
 def _random_world(rt, seed):
     """Random world of the wave-cull / grid tests: spheres from pebbles to boulders, a negative radius, moving
     spheres, triangles, squares, a cube, mirrors and glass; camera inside the cloud."""
@@ -598,6 +784,24 @@ def _random_world(rt, seed):
     cam = (A.Camera.new((6.0, -5.0, 1.5), (0.0, 0.0, 0.8)).with_fov(50.0).with_aspect(2.0).with_aperture(0.05)
            .with_focus_dist(7.0).with_sample_rate(4))
     return world, cam
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_wave_cull_random_scenes(rt, seed):
+    """Random worlds (_random_world: mirrors and glass keep narrow bundles alive over several bounces), camera inside
+    the cloud: the image with the wave-level cull must equal the image without it bit for bit."""
+    world, cam = _random_world(rt, seed)
+    W, H, depth = 256, 128, 12
+    dev = rt.default_device()
+    a, sa = world.render(cam, W, H, depth, seed=seed, return_stats=True)
+    dev.set_wave_cull(False)
+    try:
+        b, sb = world.render(cam, W, H, depth, seed=seed, return_stats=True)
+    finally:
+        dev.set_wave_cull(True)
+    assert np.array_equal(a, b)
+    assert list(sa.rays_per_level[: int(sa.levels)]) == list(sb.rays_per_level[: int(sb.levels)])
+    assert int(sa.rays) > 2 * W * H * 4          # paths do bounce
 
 
 @pytest.mark.parametrize("name,W,H,spp,depth", [("s500", 640, 360, 4, 50), ("s500", 96, 54, 8, 50), ("scene_rs", 320, 200, 4, 10),
@@ -931,7 +1135,9 @@ def test_grid_far_origins_go_to_the_rescan(rt):
         dev.set_grid(1)
     assert np.array_equal(out[0][0], out[1][0])
     assert list(out[0][1].rays_per_level[:depth]) == list(out[1][1].rays_per_level[:depth])
-    assert int(out[1][1].exact_rescan) > int(out[0][1].exact_rescan) + 1000   # the far bounce rays@pytest.mark.gpu
+    assert int(out[1][1].exact_rescan) > int(out[0][1].exact_rescan) + 1000   # the far bounce rays
+
+
 def test_tile_lists_random_cameras(rt):
     """The per-tile lists against cameras picked to break the binning: inside and outside the cloud of primitives,
     looking up, down and along the ground, fov from 15 to 140 degrees, pinhole to the widest lens the lists accept,
@@ -963,7 +1169,6 @@ def test_tile_lists_random_cameras(rt):
         assert list(res[0][1].rays_per_level[:4]) == list(res[1][1].rays_per_level[:4]), case
 
 
-@pytest.mark.gpu
 def test_tile_lists_are_exact(rt):
     """Primary rays of a tiled frame (width % 32 == 0, height % 8 == 0) scan per-tile primitive lists built per render
     call from the primitives' bounding spheres, the lens and the tile pyramids.  The lists must be supersets of what

@@ -122,8 +122,29 @@ def test_sample_range(rt):
         assert max(sizes) - min(sizes) <= 1
 
 
-def test_square_from_points_is_rejected(rt):
-    """Square::from_points' tri0-first rule (object.rs:169-174,192) has no device counterpart: refused, not guessed."""
-    import pytest
-    with pytest.raises(NotImplementedError):
-        rt.Square.from_points((0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0.5))
+def test_square_from_points_flattens_as_a_pair(rt, orc):
+    """Square::from_points (object.rs:169-174): tri0 = (p0,p1,p2), tri1 = (p1,p2,p3), hit = tri0.or(tri1) (object.rs:192).
+    The host mirror flags the pair (tri_first) for the device; the oracle's Square reproduces the rule: where both
+    triangles are hit the square reports tri0's hit although tri1's is nearer."""
+    p = [(0.0, 0.0, 0.0), (2.0, 0.0, 0.0), (0.0, 2.0, 0.0), (0.5, 0.5, 1.0)]     # tri1 rises above tri0
+    w = rt.World.empty()
+    w.add_obj(rt.Object(rt.Sphere((5, 5, 5), 0.1), rt.LambertianModel(0.5)))
+    w.add_obj(rt.Object(rt.Square.from_points(*p), rt.LambertianModel(0.5)))
+    w.add_obj(rt.Object(rt.Square((0, 0, -3), (1, 0, 0), (0, 1, 0), 2.0), rt.LambertianModel(0.5)))
+    w.add_light(rt.LightShape(rt.Square.from_points(*[(x, y, z + 4.0) for x, y, z in p])))
+    f = w.flatten()
+    assert f.tri_first.tolist() == [-1, 0, -1, -1] and f.ltri_first.tolist() == [-1, 0]
+    assert tuple(f.tri_p0[1]) == p[1] and tuple(f.tri_p1[1]) == p[2] and tuple(f.tri_p2[1]) == p[3]
+    ow = orc.OracleWorld(w)
+    # straight down through (0.6, 0.6): meets tri1 (z ~ 0.8) first, then tri0 (z = 0) - the square reports tri0
+    ray = np.array([[0.6, 0.6, 5.0, 0.0, 0.0, -1.0]])
+    ids, t, nrm, pt, fl = ow.hit(ray)
+    assert ids[0] == 1 and t[0] == 5.0 and nrm[0].tolist() == [0.0, 0.0, 1.0]
+    out = (C.c_double * 14)()
+    assert orc.lib().orc_shape_hit_info(1, orc.d3(p[1]), orc.d3(p[2]), orc.d3(p[3]), 0.0, orc.d3(ray[0, :3]), orc.d3(ray[0, 3:]), 1, out)
+    assert out[0] < 5.0                                  # tri1 alone is nearer
+    # a ray that misses tri0 (parallel to its plane) and meets tri1 only, at (0.75, 0.75, 0.5)
+    r = 2.0 ** -0.5
+    ray2 = np.array([[3.0, 3.0, 0.5, -r, -r, 0.0]])
+    ids, t, _, pt2, _ = ow.hit(ray2)
+    assert ids[0] == 1 and np.allclose(pt2[0], (0.75, 0.75, 0.5))
