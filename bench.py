@@ -16,6 +16,7 @@ Prints ONE JSON line on rank 0.
 """
 import argparse
 import glob
+import hashlib
 import importlib
 import json
 import os
@@ -85,6 +86,14 @@ def hbm_traffic_per_launch(rays_per_step, launches_per_step):
     return per_ray * rays_per_step / max(launches_per_step, 1)
 
 
+def kernel_source_hash():
+    """sha256 over the kernel sources (the first 16 hex digits): what a committed counter profile was taken from."""
+    h = hashlib.sha256()
+    for f in ("kernels.h", "cftrt.hip", "device_math.h", "scene_dev.h"):
+        h.update(open(os.path.join(ROOT, "ray-tracing_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def as_run_utilisation():
     """Instruction-based utilisation of the level kernels AS RUN (wave cull, grid) from the committed SQ counter pass
     (scripts/pmc_summary.py over `rocprofv3 --pmc SQ_*`): per kernel instance, VALU busy = SQ_ACTIVE_INST_VALU x 4 /
@@ -94,6 +103,18 @@ def as_run_utilisation():
     if not d:
         return None
     out = {"source": "profiles/" + name, "kernels": []}
+    # the profile is of the kernels as they were when it was taken: say which, and whether that is still this tree
+    meta = None
+    try:
+        meta = json.load(open(os.path.join(ROOT, "profiles", name.replace(".json", ".meta.json"))))
+    except (OSError, ValueError):
+        pass
+    out["profiled_source_sha256_16"] = meta.get("kernel_source_sha256_16") if meta else None
+    out["current_source_sha256_16"] = kernel_source_hash()
+    out["stale"] = out["profiled_source_sha256_16"] != out["current_source_sha256_16"]
+    if out["stale"]:
+        out["note"] = ("the kernel sources changed after this profile was taken (or it carries no hash): "
+                       "figures describe the profiled build, not this one")
     for e in d:
         c = e.get("largest_dispatch", {})
         if "k_trace" not in e.get("name", ""):
@@ -198,6 +219,7 @@ def main():
     # those tests; its work-delivered figure sits beside it as `delivered_equiv`.
     plain = None
     if world_size == 1 and not args.no_plain_scan and not split:
+        before = dev.settings()
         dev.set_grid(0)
         dev.set_wave_cull(0)
         dev.set_tile_lists(0)
@@ -209,15 +231,42 @@ def main():
             fence()
             dt1 = time.perf_counter() - t1
         finally:
-            dev.set_grid(1)
-            dev.set_wave_cull(1)
-            dev.set_tile_lists(1)
+            dev.restore(before)       # (whatever the CFTRT_* environment had chosen, not constants)
         pms = sum(x.ms_intersect for x in ps)
         pach = sum(x.flops for x in ps) / (pms * 1e-3) / 1e12
         pl = sum(int(x.launches_intersect) for x in ps)
         plain = {"achieved": pach, "frac": pach / PEAK_FP32_VALU_TFLOPS, "launches": pl, "avg_launch_ms": pms / max(pl, 1),
                  "algorithmic_flops_per_launch": sum(x.flops for x in ps) / max(pl, 1),
                  "ms_per_step": dt1 / 2 * 1e3, "mrays_per_s": sum(int(x.rays) for x in ps) / dt1 / 1e6}
+
+    # N > 1 only: the other reading of the metric ("1080p 64 spp at 1/2/4/8 GPU") in the same run - the 64 samples of ONE
+    # frame split over the ranks (strong scaling) when the headline ran weak, and the other way round; timed like the
+    # headline (barrier + synchronize on both sides, MAX over ranks below).
+    other = None
+    if distributed:
+        other_mode = "strong" if args.scaling == "weak" else "weak"
+        spp_other = spp if other_mode == "strong" else spp * world_size
+
+        def step_other():
+            accum.zero_()
+            torch.cuda.synchronize()
+            last["st"] = None
+            rt.multi.render_sharded(render_range, spp_other, accum, dist=dist, dst=0)
+            return last["st"]
+
+        step_other()
+        fence()
+        t2 = time.perf_counter()
+        so = [step_other() for _ in range(args.steps)]
+        fence()
+        dt2 = time.perf_counter() - t2
+        so = [x for x in so if x is not None]
+        tt = torch.tensor([dt2, float(sum(int(x.rays) for x in so))], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        other = {"scaling": other_mode, "spp_in_all": spp_other, "value": float(tt[1].item()) / float(tmax[0].item()) / 1e6,
+                 "unit": "Mrays/s", "ms_per_step": float(tmax[0].item()) / args.steps * 1e3, "steps": args.steps}
 
     rays = sum(int(s.rays) for s in stats)
     t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
@@ -237,14 +286,19 @@ def main():
         kernel = "k_intersect" if split else "k_trace_level"
         roof = {"bound": "valu_fp32", "kernel": kernel, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s"}
         if plain:
+            roof["plain_scan"] = {"achieved": plain["achieved"], "frac": plain["frac"], "ms_per_step": plain["ms_per_step"],
+                                  "mrays_per_s": plain["mrays_per_s"], "launches": plain["launches"],
+                                  "avg_launch_ms": plain["avg_launch_ms"]}
             roof.update({"achieved": plain["achieved"], "frac": plain["frac"], "launches": plain["launches"],
                          "avg_launch_ms": plain["avg_launch_ms"],
                          "algorithmic_flops_per_launch": plain["algorithmic_flops_per_launch"],
                          "flops_per_ray": 16 * 500 + 200,
                          "basis": "executed work: the level kernel as the reference's plain linear scan (wave cull and grid "
                                   "off; every ray tests every sphere, so SURVEY 8d's 16 flop x 500 spheres + 200 per ray are "
-                                  "the flops executed), timed live with HIP events in an extra leg of this run "
-                                  "(plain_scan_ms_per_step); the timed `value` runs the default path, see delivered_equiv",
+                                  "the flops executed), timed live with HIP events in an extra leg of this run, all "
+                                  "level launches and k_trace_finish in the denominator (= roofline.plain_scan); the "
+                                  "timed `value` runs the default path (cone cull, tile lists, grid), whose kernels "
+                                  "skip most of those tests: its figures are delivered_equiv and as_run_utilisation",
                          "plain_scan_ms_per_step": plain["ms_per_step"], "plain_scan_mrays_per_s": plain["mrays_per_s"]})
         else:
             roof.update({"achieved": None, "frac": None,
@@ -285,6 +339,8 @@ def main():
                                    "device_total": sum(s.ms_total for s in stats) / nst,
                                    "launches_per_step": n_launch / nst},
         }
+        if other:
+            out[other["scaling"]] = other
         if world_size == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

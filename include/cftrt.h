@@ -186,10 +186,11 @@ int cftrt_scene_set_lights(cftrt_scene* scene, const cftrt_light* lights, int64_
 /* Square::from_points (src/object.rs:169-174): its two triangles (p0,p1,p2), (p1,p2,p3) need not share a plane, and
  * Square::hit_info is `tri0.hit_info(ray).or(tri1.hit_info(ray))` (object.rs:192): the second triangle counts only
  * where the first is NOT hit, whatever the two distances (Square::new squares are planar and share only the diagonal,
- * so for them the rule is the closest of the two - they need no entry here).  tri_first[i] = index of the triangle
- * (among those of cftrt_scene_set_triangles, < i, same obj_id) that shadows triangle i this way, -1 for every other
- * triangle; ltri_first likewise over the light-shape triangles of cftrt_scene_set_lights (both triangles in one
- * light).  Optional; n_tri / n_ltri must equal the triangle counts at commit (0 with NULL: no pairs of that kind). */
+ * so for them the rule is the closest of the two - they need no entry here).  tri_first[i] = i - 1 where triangle i
+ * (of cftrt_scene_set_triangles) is the SECOND triangle of such a square and triangle i - 1, of the same obj_id, its
+ * first; -1 for every other triangle.  ltri_first likewise over the light-shape triangles of cftrt_scene_set_lights
+ * (both triangles in one light).  Optional; n_tri / n_ltri must equal the triangle counts at commit (0 with NULL: no
+ * pairs of that kind). */
 int cftrt_scene_set_triangle_pairs(cftrt_scene* scene, const int32_t* tri_first, int64_t n_tri,
                                    const int32_t* ltri_first, int64_t n_ltri);
 /* Spheres with |radius| >= this are tested in f64 for every ray (default 25). */

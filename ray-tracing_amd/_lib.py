@@ -105,6 +105,8 @@ def load():
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
     for name, res, args in SYMBOLS:
+        if os.environ.get("CFTRT_LIB") and not hasattr(lib, name):
+            continue              # (experiments only: an older build of the library for an A/B on one box)
         fn = getattr(lib, name)   # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args

@@ -349,6 +349,17 @@ class Device:
         self.h = h
         self.index = index
         self._worlds = weakref.WeakSet()   # worlds with a scene on this ctx: destroyed before the ctx
+        # what the switches are set to (the C ABI has setters only): settings() / restore() for callers that change
+        # them for a while
+        self._set = {"pipeline": 0, "wave_cull": 1, "grid": 1, "tile_lists": 1, "shards": 1, "finish": (1, 1 << 20), "variant": 0}
+
+    def settings(self):
+        return dict(self._set)
+
+    def restore(self, st):
+        self.set_pipeline(st["pipeline"]); self.set_wave_cull(st["wave_cull"]); self.set_grid(st["grid"])
+        self.set_tile_lists(st["tile_lists"]); self.set_shards(st["shards"]); self.set_finish(*st["finish"])
+        self.set_variant(st["variant"])
 
     def check(self, rc):
         if rc != 0:
@@ -360,28 +371,34 @@ class Device:
     def set_pipeline(self, split):
         """False/0 = fused k_trace_level per level (default), True/1 = k_intersect + k_shade with hit records."""
         self.check(self.lib.cftrt_ctx_set_pipeline(self.h, int(bool(split))))
+        self._set["pipeline"] = int(bool(split))
 
     def set_wave_cull(self, on):
         """Wave-level sphere cull of the level kernels (default on); images are identical either way."""
         self.check(self.lib.cftrt_ctx_set_wave_cull(self.h, int(bool(on))))
+        self._set["wave_cull"] = int(bool(on))
 
     def set_grid(self, mode, cells_per_prim=0.0):
         """Uniform grid (an extension to the reference's linear scan): 0 lists only, 1 (default) bounce rays walk it
         (primary rays too in scenes of more than 4096 primitives), 2 every ray; cells_per_prim > 0 sizes the grid
         of scenes committed afterwards.  Images are identical with any mode."""
         self.check(self.lib.cftrt_ctx_set_grid(self.h, int(mode), float(cells_per_prim)))
+        self._set["grid"] = int(mode)
 
     def set_tile_lists(self, on):
         """Per-tile primitive lists for the primary rays of tiled frames (default on; same image either way)."""
         self.check(self.lib.cftrt_ctx_set_tile_lists(self.h, int(bool(on))))
+        self._set["tile_lists"] = int(bool(on))
 
     def set_shards(self, on):
         """Big trace levels append through 8 counters into a segmented queue (default on); same image either way."""
         self.check(self.lib.cftrt_ctx_set_shards(self.h, int(bool(on))))
+        self._set["shards"] = int(bool(on))
 
     def set_finish(self, on, below=0):
         """Deep trace levels path by path in one launch (default on, below 2^20 live rays); same image either way."""
         self.check(self.lib.cftrt_ctx_set_finish(self.h, int(bool(on)), int(below)))
+        self._set["finish"] = (int(bool(on)), int(below) if below else self._set["finish"][1])
 
     # -- multi-GPU without torch.distributed: RCCL through the C ABI
     def comm_unique_id(self):
@@ -403,6 +420,7 @@ class Device:
 
     def set_variant(self, v):
         self.check(self.lib.cftrt_ctx_set_variant(self.h, int(v)))
+        self._set["variant"] = int(v)
 
     def close(self):
         if getattr(self, "h", None):

@@ -6,6 +6,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -34,6 +35,11 @@ struct cftrt_ctx {
   uint32_t finish_below = 1u << 20;
   int tile_lists = 1;     // 1: primary rays of tiled frames scan per-tile primitive lists built per render call (k_tile_bin)
   bool tiles_active = false;   // the lists in tile_off / tile_idx are those of the render call in progress
+  // what the lists in tile_off / tile_idx were built for: a render call with the same committed scene, camera and image
+  // size (a progressive host, the frames of a benchmark, the passes of a multi-GPU rank) takes them as they are
+  uint64_t tiles_scene = 0;    // commit serial of the scene (0: no lists)
+  unsigned char tiles_cam[96] = {0};   // the CamDev they were binned with
+  int tiles_usable = 0;        // the build decided the lists are worth using (not a scene wrapped around the camera)
   int n_cu = 256;
   // grow-only workspace
   DevBuf qa[2], qb[2], qc[2], h0[1 + CFT_MAX_LOOK], h1[1 + CFT_MAX_LOOK], ht[1 + CFT_MAX_LOOK], rad, pqa, pqb, pqc, pqd, counts, accum_tmp, misc, tile_rng, tile_cnt, tile_off, tile_idx;
@@ -102,6 +108,7 @@ struct DeviceGuard {
 struct cftrt_scene {
   cftrt_ctx* ctx = nullptr;
   bool committed = false;
+  uint64_t serial = 0;                 // unique per committed scene of the process (keys the ctx's cached tile lists)
   double precise_radius = 25.0;
   std::vector<double> sph_c, sph_r, sph_mv;
   std::vector<int32_t> sph_obj, sph_mat;
@@ -301,6 +308,7 @@ int cftrt_scene_create(cftrt_ctx* ctx, cftrt_scene** out) {
 
 void cftrt_scene_destroy(cftrt_scene* s) {
   if (!s) return;
+  if (s->ctx->tiles_scene == s->serial) s->ctx->tiles_scene = 0;
   DeviceGuard guard(s->ctx->device);
   (void)hipStreamSynchronize(s->ctx->stream);
   for (void* p : s->dev_allocs) (void)hipFree(p);
@@ -401,9 +409,11 @@ int cftrt_scene_set_triangle_pairs(cftrt_scene* s, const int32_t* tri_first, int
   if (n_tri < 0 || n_ltri < 0 || (n_tri > 0 && !tri_first) || (n_ltri > 0 && !ltri_first))
     return fail(s->ctx, CFTRT_ERR_INVALID, "set_triangle_pairs: null pointer or negative n");
   for (int64_t i = 0; i < n_tri; ++i)
-    if (tri_first[i] < -1 || tri_first[i] >= i) return fail(s->ctx, CFTRT_ERR_INVALID, "set_triangle_pairs: tri_first[i] must be -1 or an earlier triangle");
+    if (tri_first[i] != -1 && (tri_first[i] != i - 1 || i == 0 || tri_first[i - 1] != -1))
+      return fail(s->ctx, CFTRT_ERR_INVALID, "set_triangle_pairs: tri_first[i] must be -1 or i - 1 (the triangle right before, itself not a second one)");
   for (int64_t i = 0; i < n_ltri; ++i)
-    if (ltri_first[i] < -1 || ltri_first[i] >= i) return fail(s->ctx, CFTRT_ERR_INVALID, "set_triangle_pairs: ltri_first[i] must be -1 or an earlier triangle");
+    if (ltri_first[i] != -1 && (ltri_first[i] != i - 1 || i == 0 || ltri_first[i - 1] != -1))
+      return fail(s->ctx, CFTRT_ERR_INVALID, "set_triangle_pairs: ltri_first[i] must be -1 or i - 1 (the triangle right before, itself not a second one)");
   s->tri_first.assign(tri_first, tri_first + n_tri);
   s->ltri_first.assign(ltri_first, ltri_first + n_ltri);
   return CFTRT_OK;
@@ -615,6 +625,49 @@ int cftrt_scene_commit(cftrt_scene* s) {
       apply(o, triF, 3); apply(o, triF_gid, 1);
     }
   }
+  // The static triangles as scan ITEMS (kernels.h, tri_item_bounds): two neighbours of the list that are the two triangles
+  // of a Square::new - (p0, p1, p2) and (p2, p3, p0) of one object with p3 = p0 + p2 - p1, the corner order of
+  // object.rs:148-161 - become ONE parallelogram item (p0; ea = p1 - p0, eb = p3 - p0): one f32 test instead of two, whose
+  // result names the triangle(s) to hand to the exact evaluation.  Everything else (and the second triangle of a
+  // Square::from_points, which is no parallelogram half) stays a single-triangle item.
+  std::vector<float4> triItem;
+  std::vector<int> item_first;   // index in triF of each item's first triangle
+  std::vector<char> item_quad;
+  int nb_item = 0;
+  {
+    const int nT = (int)triF_gid.size();
+    for (int i = 0; i < nT;) {
+      bool quad = false;
+      float4 EB = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i + 1 < nT && (i < nb_tri) == (i + 1 < nb_tri)) {
+        const int ti = triF_gid[i] - ns, tj = triF_gid[i + 1] - ns;
+        const double* P = &s->tri_p[9 * (size_t)ti];
+        const double* Q = &s->tri_p[9 * (size_t)tj];
+        const bool flagged = !s->tri_first.empty() && (s->tri_first[(size_t)ti] >= 0 || s->tri_first[(size_t)tj] >= 0);
+        if (tj == ti + 1 && s->tri_obj[(size_t)ti] == s->tri_obj[(size_t)tj] && !flagged && !memcmp(Q, P + 6, 24) && !memcmp(Q + 6, P, 24)) {
+          double dev = 0., scale = 0.;
+          for (int k = 0; k < 3; ++k) {
+            dev = std::max(dev, std::fabs(Q[3 + k] - (P[k] + P[6 + k] - P[3 + k])));
+            scale = std::max(scale, std::max(std::fabs(P[3 + k] - P[k]), std::fabs(P[6 + k] - P[k])));
+          }
+          if (dev <= 1e-10 * scale) {
+            quad = true;
+            EB = make_float4((float)(Q[3] - P[0]), (float)(Q[4] - P[1]), (float)(Q[5] - P[2]), 0.f);
+          }
+        }
+      }
+      const int meta = (i << 1) | (quad ? 1 : 0);
+      float4 P0 = triF[3 * (size_t)i];
+      memcpy(&P0.w, &meta, 4);
+      triItem.push_back(P0);
+      triItem.push_back(triF[3 * (size_t)i + 1]);
+      triItem.push_back(quad ? EB : triF[3 * (size_t)i + 2]);
+      item_first.push_back(i);
+      item_quad.push_back(quad ? 1 : 0);
+      if (i < nb_tri) nb_item++;
+      i += quad ? 2 : 1;
+    }
+  }
   msphF.push_back(make_float4(0.f, 0.f, 0.f, -1e30f));   // the prefetched extra entry of the moving list
   msphF.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
   while (msphB.size() % 4) msphB.push_back(make_float4(0.f, 0.f, 0.f, 1e30f));
@@ -701,11 +754,16 @@ int cftrt_scene_commit(cftrt_scene* s) {
         std::vector<uint32_t> cntS(nc, 0), cntT(nc, 0);
         size_t total = 0;
         // two passes over the same enumeration: count, then fill
+        // i < nS + nM: sphere i of the lists; otherwise item i - nS - nM of the static triangles (its one or two triangles)
         auto each_cell = [&](int i, auto&& f) {
           int a[3], b[3];
+          const int t0 = i < nS + nM ? -1 : item_first[(size_t)(i - nS - nM)];
+          const int t1 = t0 >= 0 && item_quad[(size_t)(i - nS - nM)] ? t0 + 1 : t0;
           for (int k = 0; k < 3; ++k) {
-            a[k] = std::min(n[k] - 1, std::max(0, (int)std::floor((bx[i].lo[k] - margin - blo[k]) / cs[k])));
-            b[k] = std::min(n[k] - 1, std::max(0, (int)std::floor((bx[i].hi[k] + margin - blo[k]) / cs[k])));
+            const double lo_k = t0 < 0 ? bx[i].lo[k] : std::min(bx[nS + nM + t0].lo[k], bx[nS + nM + t1].lo[k]);
+            const double hi_k = t0 < 0 ? bx[i].hi[k] : std::max(bx[nS + nM + t0].hi[k], bx[nS + nM + t1].hi[k]);
+            a[k] = std::min(n[k] - 1, std::max(0, (int)std::floor((lo_k - margin - blo[k]) / cs[k])));
+            b[k] = std::min(n[k] - 1, std::max(0, (int)std::floor((hi_k + margin - blo[k]) / cs[k])));
           }
           for (int z = a[2]; z <= b[2]; ++z)
             for (int y = a[1]; y <= b[1]; ++y)
@@ -724,12 +782,14 @@ int cftrt_scene_commit(cftrt_scene* s) {
                   const int c3[3] = {x, y, z};
                   double bc3[3], bh[3];
                   for (int k = 0; k < 3; ++k) { bc3[k] = blo[k] + (c3[k] + 0.5) * cs[k]; bh[k] = 0.5 * cs[k] + margin; }
-                  if (!tri_box_overlap(bc3, bh, &triV[9 * (size_t)(i - nS - nM)])) continue;
+                  if (!tri_box_overlap(bc3, bh, &triV[9 * (size_t)t0]) && (t1 == t0 || !tri_box_overlap(bc3, bh, &triV[9 * (size_t)t1]))) continue;
                 }
                 f(((size_t)z * n[1] + y) * n[0] + x);
               }
         };
-        for (int i = 0; i < nP; ++i) if (in_grid(i)) each_cell(i, [&](size_t c) { (i < nS + nM ? cntS : cntT)[c]++; total++; });
+        const int nUnits = nS + nM + (int)item_first.size();
+        auto unit_in_grid = [&](int i) { return i < nS + nM ? in_grid(i) : in_grid(nS + nM + item_first[(size_t)(i - nS - nM)]); };
+        for (int i = 0; i < nUnits; ++i) if (unit_in_grid(i)) each_cell(i, [&](size_t c) { (i < nS + nM ? cntS : cntT)[c]++; total++; });
         if (total > 24 * (size_t)nG) continue;   // primitives much larger than the cells: coarser
         {   // the packed record holds 8 bits of count and 24 of offset
           uint32_t cmax = 0;
@@ -745,8 +805,8 @@ int cftrt_scene_commit(cftrt_scene* s) {
         gridSph.resize((size_t)oS);
         gridSphX.resize((size_t)oS);
         gridTri.resize(oT);
-        for (int i = 0; i < nP; ++i)
-          if (in_grid(i)) each_cell(i, [&](size_t c) {
+        for (int i = 0; i < nUnits; ++i)
+          if (unit_in_grid(i)) each_cell(i, [&](size_t c) {
             if (i < nS + nM) {
               const size_t e = (size_t)offS[c] + (gridCell[c].x++ & 255u);
               float ib;
@@ -791,6 +851,7 @@ int cftrt_scene_commit(cftrt_scene* s) {
   if ((rc = upload(s, prec_gid, &D.prec_gid))) return rc;
   if ((rc = upload(s, triF, &D.triF))) return rc;
   if ((rc = upload(s, triF_gid, &D.triF_gid))) return rc;
+  if ((rc = upload(s, triItem, &D.triItem))) return rc;
   if ((rc = upload(s, mtriF, &D.mtriF))) return rc;
   if ((rc = upload(s, mtri_gid, &D.mtri_gid))) return rc;
   if ((rc = upload(s, gridCell, &D.gridCell))) return rc;
@@ -856,6 +917,7 @@ int cftrt_scene_commit(cftrt_scene* s) {
   D.n_phong_mats = n_phong;
   D.gnx = G.n[0]; D.gny = G.n[1]; D.gnz = G.n[2];
   D.nb_sph = nb_sph; D.nb_msph = nb_msph; D.nb_tri = nb_tri;
+  D.n_item = (int)item_first.size(); D.nb_item = nb_item;
   D.grid_mode = 0;   // set per pass from the ctx (cftrt_ctx_set_grid)
   if (G.n[0]) {
     // the box as the kernel sees it: low corner rounded down, high corner up (the box only grows)
@@ -917,6 +979,8 @@ int cftrt_scene_commit(cftrt_scene* s) {
             gridSph.size(), gridTri.size(), cmaxS, cmaxT);
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  static std::atomic<uint64_t> next_serial{1};
+  s->serial = next_serial.fetch_add(1);
   s->committed = true;
   return CFTRT_OK;
 }
@@ -1028,7 +1092,8 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
 #undef CFT_TAIL
     return;
   }
-  const uint32_t g = grid_for(ctx, ((uint64_t)P + R - 1) / R, 8);
+  static const uint32_t blocks_per_cu = getenv("CFTRT_BLOCKS_PER_CU") ? (uint32_t)atoi(getenv("CFTRT_BLOCKS_PER_CU")) : 8u;   // (experiments)
+  const uint32_t g = grid_for(ctx, ((uint64_t)P + R - 1) / R, blocks_per_cu);
   const GenArgs no_gen{};
   // (experiments: unused dynamic LDS per block lowers the number of resident blocks per CU)
   static const uint32_t dyn_lds = getenv("CFTRT_EXTRA_LDS") ? (uint32_t)atoi(getenv("CFTRT_EXTRA_LDS")) : 0u;
@@ -1247,6 +1312,12 @@ static int build_tile_lists(cftrt_scene* s, const CamDev& C, const cftrt_camera*
     const double fd = cam->focus_dist * ls;   // (up to the tilt of a non-orthogonal `up`: a factor the 1/8 absorbs)
     if (!(fd > 0.) || !(0.5 * std::fabs(cam->aperture) * (1. + lu) * 1.0001 < 0.125 * fd)) return CFTRT_OK;
   }
+  static_assert(sizeof(CamDev) <= sizeof(ctx->tiles_cam), "tiles_cam holds a CamDev");
+  if (ctx->tiles_scene == s->serial && !memcmp(ctx->tiles_cam, &C, sizeof C)) {   // same scene, camera and size: keep them
+    ctx->tiles_active = ctx->tiles_usable != 0;
+    return CFTRT_OK;
+  }
+  ctx->tiles_scene = 0;
   int rc;
   if ((rc = ensure(ctx, ctx->tile_rng, (size_t)n * sizeof(TileRange)))) return rc;
   if ((rc = ensure(ctx, ctx->tile_cnt, (size_t)nt * 4))) return rc;
@@ -1260,6 +1331,10 @@ static int build_tile_lists(cftrt_scene* s, const CamDev& C, const cftrt_camera*
   uint32_t total = 0;
   HIP_TRY(ctx, hipMemcpyAsync(&total, (uint32_t*)ctx->tile_off.p + nt, 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
+  memset(ctx->tiles_cam, 0, sizeof ctx->tiles_cam);
+  memcpy(ctx->tiles_cam, &C, sizeof C);
+  ctx->tiles_usable = 0;
+  ctx->tiles_scene = s->serial;
   if ((uint64_t)total * 4 > (1ull << 30)) return CFTRT_OK;   // (a scene wrapped around the camera: not worth a GiB of lists)
   if ((rc = ensure(ctx, ctx->tile_idx, std::max<size_t>((size_t)total * 4, 256)))) return rc;
   hipLaunchKernelGGL(k_tile_bin, dim3(g), dim3(CFT_BLOCK), 0, st, C, S.boundF, (const float4*)S.triF, (uint32_t)(S.n_sphF + S.n_msph), n, S.bcx, S.bcy, S.bcz, ntx, nty,
@@ -1268,6 +1343,7 @@ static int build_tile_lists(cftrt_scene* s, const CamDev& C, const cftrt_camera*
   HIP_TRY(ctx, hipGetLastError());
   if (getenv("CFTRT_DEBUG"))
     fprintf(stderr, "cftrt tile lists: %u primitives, %u x %u tiles, %u entries (%.1f per tile)\n", n, ntx, nty, total, (double)total / nt);
+  ctx->tiles_usable = 1;
   ctx->tiles_active = true;
   return CFTRT_OK;
 }

@@ -139,7 +139,8 @@ __device__ __forceinline__ d3 ld3(const double* p) { return d3{p[0], p[1], p[2]}
 
 // Exact test of global prim g for this ray and scan (motion time keyed by the owning object).
 __device__ __forceinline__ bool exact_prim(const SceneDev& S, int g, d3 o, d3 d, uint32_t scan_word,
-                                           double* t_out) {
+                                           double* t_out, int* g_hit = nullptr) {
+  if (g_hit) *g_hit = g;
   if (g < S.n_sph) {
     const double* sp = S.sphD + 4 * (size_t)g;
     d3 c = ld3(sp);
@@ -152,30 +153,34 @@ __device__ __forceinline__ bool exact_prim(const SceneDev& S, int g, d3 o, d3 d,
     }
     return exact_sphere(o, d, c, sp[3], t_out);
   }
+  // Triangles.  The two triangles of a Square::from_points (object.rs:169-174) are evaluated as the reference evaluates
+  // the square, tri0.or(tri1) (object.rs:192): whichever of the two is asked for, the first triangle is tested first and
+  // the second only where the first is not hit - so the second never counts where the first is hit, whatever the
+  // distances, and the answer is the square's own hit.  One exact_tri call site in a loop of at most two rounds (a second
+  // inlined copy cost every level kernel 30-50 bytes of scratch per lane).  *g_hit = the triangle actually hit.
   int ti = g - S.n_sph;
-  const double* tp = S.triD + 9 * (size_t)ti;
-  d3 p0 = ld3(tp), p1 = ld3(tp + 3), p2 = ld3(tp + 6);
-  d3 dl = d3{0., 0., 0.};
-  if (S.any_motion) {
-    d3 mv = ld3(S.triMvD + 3 * (size_t)ti);
-    if (mv.x != 0. || mv.y != 0. || mv.z != 0.) {
-      double tm = (double)motion_time(scan_word, (uint32_t)S.prim_obj[g]);
-      d3 delta = mv * tm;
-      p0 = p0 + delta; p1 = p1 + delta; p2 = p2 + delta;
-      dl = delta;
-    }
+  int last = ti;
+  if (S.any_pairs) {
+    if (S.tri_first[ti] >= 0) ti -= 1;                                   // asked for the second: start at the first
+    last = (ti + 1 < S.n_tri && S.tri_first[ti + 1] >= 0) ? ti + 1 : ti;   // a pair: its second triangle comes next
   }
-  bool hit = exact_tri(o, d, p0, p1, p2, t_out);
-  if (S.any_pairs && hit) {
-    // the second triangle of a Square::from_points: no hit where the first one is hit (tri0.or(tri1), object.rs:192);
-    // both belong to one object, so they move by the same delta
-    const int f = S.tri_first[ti];
-    if (f >= 0) {
-      const double* fp = S.triD + 9 * (size_t)f;
-      double t0;
-      if (exact_tri(o, d, ld3(fp) + dl, ld3(fp + 3) + dl, ld3(fp + 6) + dl, &t0)) hit = false;
+  bool hit;
+  for (;;) {
+    const double* tp = S.triD + 9 * (size_t)ti;
+    d3 p0 = ld3(tp), p1 = ld3(tp + 3), p2 = ld3(tp + 6);
+    if (S.any_motion) {
+      d3 mv = ld3(S.triMvD + 3 * (size_t)ti);
+      if (mv.x != 0. || mv.y != 0. || mv.z != 0.) {
+        double tm = (double)motion_time(scan_word, (uint32_t)S.prim_obj[S.n_sph + ti]);
+        d3 delta = mv * tm;
+        p0 = p0 + delta; p1 = p1 + delta; p2 = p2 + delta;
+      }
     }
+    hit = exact_tri(o, d, p0, p1, p2, t_out);
+    if (hit || ti >= last) break;
+    ti += 1;
   }
+  if (g_hit) *g_hit = S.n_sph + ti;
   return hit;
 }
 
@@ -204,9 +209,10 @@ __device__ __forceinline__ void exact_scan_all_wave_call(const SceneDev& S, bool
     int bg = 0x7fffffff, bobj = 0x7fffffff;
     for (int g = rank; g < n; g += nact) {
       double t;
-      if (!exact_prim(S, g, ro, rd, rw, &t)) continue;
+      int gh;
+      if (!exact_prim(S, g, ro, rd, rw, &t, &gh)) continue;
       const int obj = S.prim_obj[g];
-      if (t < bt || (t == bt && obj < bobj)) { bt = t; bg = g; bobj = obj; }   // g ascends: the first of equals stays
+      if (t < bt || (t == bt && obj < bobj)) { bt = t; bg = gh; bobj = obj; }   // g ascends: the first of equals stays
     }
     // the winners of the active lanes, one by one (uniform values; every lane ends with the same result)
     double wt = __builtin_inf();
@@ -343,6 +349,64 @@ __device__ __forceinline__ float tri_lower_bound(const SceneDev& S, float ox, fl
     }
   }
   return r;
+}
+
+// One ITEM of the static triangle scan: a single triangle (p0, e1, e2), or - quad - the two triangles of a Square::new
+// as ONE parallelogram (p0; ea, eb): tri0 = (p0, p0 + ea, p0 + ea + eb) and tri1 = (p0 + ea + eb, p0 + eb, p0), the
+// reference's corner order (object.rs:148-161).  Both triangles lie in the parallelogram's plane and their
+// determinant e1.(d x e2) equals ea.(d x eb), so one Moller-Trumbore evaluation in the parallelogram's coordinates
+// (point = p0 + u ea + v eb) serves both: tri0 is the half v <= u, tri1 the half v >= u (with tri0's own barycentrics
+// (u', v') the point is p0 + u' ea + v' (ea + eb), i.e. u = u' + v', v = v': u' >= 0, v' >= 0, u' + v' <= 1 read
+// u - v >= 0, v >= 0, u <= 1).  Same error margins as tri_lower_bound (|u, v - true| <= mu each, |t - true| <= mt; the
+// constants cover edges up to the longest edge of any triangle, the diagonal included, and the <= 1e-10 relative by
+// which a square's fourth corner may miss p0 + ea + eb - p1 in f64).  Out: *c0 / *c1 = the item's first / second
+// triangle may be hit no farther than U (a single triangle only ever sets *c0), *tlo = the lower bound on that
+// distance; *thi = an upper bound when one of them certainly is hit (untouched otherwise).
+__device__ __forceinline__ void tri_item_bounds(const SceneDev& S, float ox, float oy, float oz, float dx, float dy, float dz,
+                                                f3 p0, f3 e1, f3 e2, bool quad, float U, bool* c0, bool* c1, float* tlo,
+                                                float* thi = nullptr) {
+  const f3 d = mk3(dx, dy, dz);
+  const f3 h = cross3(d, e2);
+  const float a = dot3(e1, h);
+  *c0 = false; *c1 = false; *tlo = 0.0f;
+  if (fabsf(a) >= CFT_EPS - S.tKA) {                    // the reference rejects |a| < EPS (object.rs:105)
+    const float f = __builtin_amdgcn_rcpf(a);
+    const float af = fabsf(f);
+    const f3 s = mk3(ox - p0.x, oy - p0.y, oz - p0.z);
+    const float s1 = fabsf(s.x) + fabsf(s.y) + fabsf(s.z);
+    const float u = f * dot3(s, h);
+    const f3 q = cross3(s, e1);
+    const float v = f * dot3(d, q);
+    const float t = f * dot3(e2, q);
+    const float mu = af * fmaf(s1, S.tKU1, S.tKU2);
+    const float mt = af * fmaf(fabsf(t), S.tKT3, fmaf(s1, S.tKT1, S.tKT2));
+    const float tl = fmaxf(t - mt, 0.0f);
+    const bool reach = t + mt > CFT_EPS && tl <= U;
+    const bool sure = thi && fabsf(a) >= CFT_EPS + S.tKA && t - mt > CFT_EPS;
+    bool in0, in1 = false, sure_in;
+    if (!quad) {
+      in0 = u >= -mu && v >= -mu && u <= 1.0f + mu && u + v <= 1.0f + 2.0f * mu;
+      sure_in = u >= mu && v >= mu && u + v <= 1.0f - 2.0f * mu;
+    } else {
+      const float w = u - v;
+      in0 = v >= -mu && w >= -2.0f * mu && u <= 1.0f + mu;
+      in1 = u >= -mu && w <= 2.0f * mu && v <= 1.0f + mu;
+      sure_in = (v >= mu && w >= 2.0f * mu && u <= 1.0f - mu) || (u >= mu && w <= -2.0f * mu && v <= 1.0f - mu);
+    }
+    *c0 = in0 && reach; *c1 = in1 && reach; *tlo = tl;
+    if (sure && sure_in) *thi = t + mt;
+  }
+}
+
+// The static triangle items of the lists, 3 float4 each: (p0', meta bits), (e1 | ea), (e2 | eb); meta = (index of the
+// item's first triangle in the triF list << 1) | quad.
+struct TriItem { f3 p0, e1, e2; bool quad; int first; };
+__device__ __forceinline__ TriItem tri_item(float4 a, float4 b, float4 c) {
+  const int meta = __float_as_int(a.w);
+  return TriItem{mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), (meta & 1) != 0, meta >> 1};
+}
+__device__ __forceinline__ TriItem tri_item(v4f a, v4f b, v4f c) {
+  return tri_item(make_float4(a[0], a[1], a[2], a[3]), make_float4(b[0], b[1], b[2], b[3]), make_float4(c[0], c[1], c[2], c[3]));
 }
 
 // A path's radiance as it waits for k_resolve: 12 bytes (the resolve pass runs at the HBM's speed, a fourth float of
@@ -732,7 +796,13 @@ __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>&
 #endif
         const uint32_t e = e0 + (uint32_t)__builtin_ctz(pass);
         pass &= pass - 1u;
+#ifdef CFT_X4
+        float4 a = a4[0];
+#pragma unroll
+        for (int j = 1; j < CFT_WALK_BATCH; ++j) if (e - e0 == (uint32_t)j) a = a4[j];
+#else
         const float4 a = S.gridSph[e];    // (again: the batch sits in registers under a constant index only)
+#endif
         const float2 b = S.gridSphX[e];   // (16 r^2, list index)
         const int idx = __float_as_int(b.y);
         bool seen = true;
@@ -749,15 +819,16 @@ __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>&
     }
     if (LISTS & 2) {
       for (uint32_t e = cell.y >> 12, ee = (cell.y >> 12) + ((cell.y >> 4) & 255u); e < ee; ++e) {
-        const int s = (int)S.gridTri[e];
-        const float4 p0 = S.triF[3 * s], e1 = S.triF[3 * s + 1], e2 = S.triF[3 * s + 2];
-        float thi = inf;
-        const float tlo = tri_lower_bound(S, ox, oy, oz, dx, dy, dz, mk3(p0.x, p0.y, p0.z), mk3(e1.x, e1.y, e1.z),
-                                          mk3(e2.x, e2.y, e2.z), P.U[r], &thi);
-        if (tlo >= 0.0f) {
+        const int s = (int)S.gridTri[e];   // an item: one triangle, or the two of a square as one parallelogram
+        const TriItem it = tri_item(S.triItem[3 * s], S.triItem[3 * s + 1], S.triItem[3 * s + 2]);
+        float thi = inf, tlo;
+        bool c0, c1;
+        tri_item_bounds(S, ox, oy, oz, dx, dy, dz, it.p0, it.e1, it.e2, it.quad, P.U[r], &c0, &c1, &tlo, &thi);
+        if (c0 || c1) {
 #pragma unroll
           for (int k = 0; k < NS; ++k) {
-            cand_offer<true>(P.c[k][r], tlo, S.n_sphF + S.n_msph + s);
+            if (c0) cand_offer<true>(P.c[k][r], tlo, S.n_sphF + S.n_msph + it.first);
+            if (c1) cand_offer<true>(P.c[k][r], tlo, S.n_sphF + S.n_msph + it.first + 1);
             hi[k] = fminf(hi[k], thi);
           }
         }
@@ -792,6 +863,24 @@ __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>&
     atomicAdd(&g_walk_stats[26], (unsigned long long)wk_xcand); atomicAdd(&g_walk_stats[27], (unsigned long long)wk_batches);
   }
 #endif
+}
+
+// One static triangle item (wave-uniform: its data sit in SGPRs) against the R rays of a lane.
+template <int R, int NS>
+__device__ __forceinline__ void scan_tri_item(const SceneDev& S, RayPack<R, NS>& P, const TriItem it) {
+  const int base = S.n_sphF + S.n_msph + it.first;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    bool c0, c1;
+    float tlo;
+    tri_item_bounds(S, 0.25f * PK(P, o4x, r), 0.25f * PK(P, o4y, r), 0.25f * PK(P, o4z, r), PK(P, dx, r), PK(P, dy, r),
+                    PK(P, dz, r), it.p0, it.e1, it.e2, it.quad, P.U[r], &c0, &c1, &tlo);
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      if (c0) cand_insert(P.c[k][r], tlo, base);
+      if (c1) cand_insert(P.c[k][r], tlo, base + 1);
+    }
+  }
 }
 
 // Moving triangles (4 float4 each: p0, e1, e2, (mv, object id)), once per scan with that scan's motion time.
@@ -924,20 +1013,8 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P,
         scan_msphere<R, NS>(S, P, v2f{sb[0], sb[1]}, v2f{sb[2], sb[3]}, i);
       }
     if (LISTS & 2) {
-      c_f4p tp = AS_CONST(c_f4p, S.triF);
-      for (int s = 0; s < S.nb_tri; ++s) {
-        const v4f a = tp[3 * s], b = tp[3 * s + 1], cc = tp[3 * s + 2];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const float tlo = tri_lower_bound(S, 0.25f * PK(P, o4x, r), 0.25f * PK(P, o4y, r), 0.25f * PK(P, o4z, r), PK(P, dx, r),
-                                            PK(P, dy, r), PK(P, dz, r), mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z),
-                                            mk3(cc.x, cc.y, cc.z), P.U[r]);
-          if (tlo >= 0.0f) {
-#pragma unroll
-            for (int k = 0; k < NS; ++k) cand_insert(P.c[k][r], tlo, S.n_sphF + S.n_msph + s);
-          }
-        }
-      }
+      c_f4p tp = AS_CONST(c_f4p, S.triItem);
+      for (int s = 0; s < S.nb_item; ++s) scan_tri_item<R, NS>(S, P, tri_item(tp[3 * s], tp[3 * s + 1], tp[3 * s + 2]));
       scan_mtris<R, NS>(S, P, S.n_sphF + S.n_msph + S.n_triF, 0, 1);
     }
 #pragma unroll
@@ -1026,31 +1103,21 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P,
   }
   base += S.n_msph;
   if (LISTS & 2) {
-    c_f4p tp = AS_CONST(c_f4p, S.triF);
-    const int n = S.n_triF * (part + 1) / nparts;
-    const int lo = S.n_triF * part / nparts;
-    auto one = [&](int s) {
-      v4f a = tp[3 * s], b = tp[3 * s + 1], cc = tp[3 * s + 2];
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        float tlo = tri_lower_bound(S, 0.25f * PK(P, o4x, r), 0.25f * PK(P, o4y, r), 0.25f * PK(P, o4z, r), PK(P, dx, r),
-                                    PK(P, dy, r), PK(P, dz, r), mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z),
-                                    mk3(cc.x, cc.y, cc.z), P.U[r]);
-        if (tlo >= 0.0f) {
-#pragma unroll
-          for (int k = 0; k < NS; ++k) cand_insert(P.c[k][r], tlo, base + s);
-        }
-      }
-    };
+    c_f4p tp = AS_CONST(c_f4p, S.triItem);
+    const int n = S.n_item * (part + 1) / nparts;
+    const int lo = S.n_item * part / nparts;
+    auto one = [&](int s) { scan_tri_item<R, NS>(S, P, tri_item(tp[3 * s], tp[3 * s + 1], tp[3 * s + 2])); };
     if (cull) {
-      // bound of the triangle: sphere around p0 + (e1 + e2)/3 through the farthest vertex
+      // bound of the item: a triangle - sphere around p0 + (e1 + e2)/3 through the farthest vertex; a parallelogram -
+      // sphere around its centre p0 + (ea + eb)/2 through the corners (half the longer diagonal)
       const int lane = (int)(threadIdx.x & 63u);
       for (int s0 = lo; s0 < n; s0 += 64) {
         const int idx = s0 + lane;
         bool pass = false;
         if (idx < n) {
-          const float4 p0 = S.triF[3 * idx], e1 = S.triF[3 * idx + 1], e2 = S.triF[3 * idx + 2];
-          const float gx = (e1.x + e2.x) * (1.0f / 3.0f), gy = (e1.y + e2.y) * (1.0f / 3.0f), gz = (e1.z + e2.z) * (1.0f / 3.0f);
+          const float4 p0 = S.triItem[3 * idx], e1 = S.triItem[3 * idx + 1], e2 = S.triItem[3 * idx + 2];
+          const float k = (__float_as_int(p0.w) & 1) ? 0.5f : (1.0f / 3.0f);
+          const float gx = (e1.x + e2.x) * k, gy = (e1.y + e2.y) * k, gz = (e1.z + e2.z) * k;
           const float r0 = fmaf(gz, gz, fmaf(gy, gy, gx * gx));
           const float r1 = fmaf(e1.z - gz, e1.z - gz, fmaf(e1.y - gy, e1.y - gy, (e1.x - gx) * (e1.x - gx)));
           const float r2 = fmaf(e2.z - gz, e2.z - gz, fmaf(e2.y - gy, e2.y - gy, (e2.x - gx) * (e2.x - gx)));
@@ -1162,7 +1229,7 @@ __device__ __forceinline__ bool exact_list_prim(const SceneDev& S, int li, d3 o,
     w->geom = true;
     return exact_sphere(o, d, c, w->rad, t_out);
   }
-  return exact_prim(S, rec.x, o, d, scan_word, t_out);   // triangles: by prim id
+  return exact_prim(S, rec.x, o, d, scan_word, t_out, &w->g);   // triangles: by prim id (w->g: the triangle hit - a Square::from_points answers as a pair)
 }
 
 // After the scan: exact evaluation of the two best candidates, rescan if a third could still win.
@@ -1182,7 +1249,11 @@ __device__ __forceinline__ Winner ray_epilogue_w(const SceneDev& S, float ox, fl
   // scan happened to rank first (the per-tile lists are filled through atomics, in no fixed order).
   auto wins_tie = [&](const Winner& w, const Winner& cur) {
     const int a = w.obj, b = obj_of(cur);
+#ifdef CFT_OLD_TIE
+    return a < b;
+#else
     return a < b || (a == b && w.g < cur.g);
+#endif
   };
   if (c.i1 >= 0) {
     Winner w;
@@ -1797,20 +1868,15 @@ __device__ __forceinline__ bool light_shape_hit(const SceneDev& S, const LightDe
     double t;
     if (exact_sphere(o, d, ld3(sp), sp[3], &t) && t < bt) { bt = t; any = true; }
   }
+  bool prev_hit = false;
   for (int k = 0; k < L.tri_count; ++k) {
     const double* tp = S.ltriD + 9 * (size_t)(L.tri_begin + k);
     double t;
-    if (exact_tri(o, d, ld3(tp), ld3(tp + 3), ld3(tp + 6), &t)) {
-      if (S.any_pairs) {   // LightShape(Square::from_points): tri0.or(tri1), as in exact_prim
-        const int f = S.ltri_first[L.tri_begin + k];
-        if (f >= 0) {
-          const double* fp = S.ltriD + 9 * (size_t)f;
-          double t0;
-          if (exact_tri(o, d, ld3(fp), ld3(fp + 3), ld3(fp + 6), &t0)) continue;
-        }
-      }
-      if (t < bt) { bt = t; any = true; }
-    }
+    // (LightShape(Square::from_points): tri0.or(tri1) - the second triangle, which follows its first, does not count
+    // where the first was hit)
+    if (S.any_pairs && prev_hit && S.ltri_first[L.tri_begin + k] >= 0) { prev_hit = false; continue; }
+    prev_hit = exact_tri(o, d, ld3(tp), ld3(tp + 3), ld3(tp + 6), &t);
+    if (prev_hit && t < bt) { bt = t; any = true; }
   }
   *t_out = bt;
   return any;
@@ -2274,11 +2340,13 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(LevelArgs) {
         hit.b0 = hit.a0;
         double tb = hit.ta;
         if (NS == 2) isect_hit<NS>(S, live, r, 1, a.x, a.y, a.z, a.w, b.x, b.y, park, A.stats, &hit.b0, &hit.b1, &tb, &hit.mat_id);
+#ifndef CFT_NO_DBG
         if (A.dbg_t != nullptr && live) {   // (wave-uniform pointer test; never taken in a render call)
           const size_t w0 = (size_t)NS * __float_as_uint(c.y);
           A.dbg_t[w0] = hit.ta; A.dbg_prim[w0] = __float_as_int(hit.a0.y);
           if (NS == 2) { A.dbg_t[w0 + 1] = tb; A.dbg_prim[w0 + 1] = __float_as_int(hit.b0.y); }
         }
+#endif
         CFT_STAMP(4);   // (diagnostic build: "park" = the exact evaluation and hit record of the slots; "epilogue" = shading)
         f3 thr = mk3(b.z, b.w, c.x), npos, ndir;
         const bool alive = live && shade_one(S, hit, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), &thr, __float_as_uint(c.y), A.level,

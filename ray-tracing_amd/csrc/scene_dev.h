@@ -38,6 +38,11 @@ struct SceneDev {
   const float4* triF;     // static triangles, 3 float4 each: (p0, -), (e1, -), (e2, -)
   const int* triF_gid;
   int n_triF;
+  // the same triangles as the ITEMS the scans test: a single triangle, or the two triangles of a Square::new as one
+  // parallelogram (kernels.h, tri_item_bounds).  3 float4 each: (p0, meta bits), (e1 | ea), (e2 | eb); meta = (index in
+  // triF of the item's first triangle << 1) | quad; a quad's second triangle is the next entry of triF.
+  const float4* triItem;
+  int n_item, nb_item;    // the first nb_item items are too big for the grid (scanned linearly by every ray)
   const float4* mtriF;    // moving triangles, 4 float4 each: p0, e1, e2, (mv, object id bits)
   const int* mtri_gid;
   int n_mtri;
@@ -45,7 +50,7 @@ struct SceneDev {
   const uint2* gridCell;  // x = (first sphere entry << 8) | count; y = (first triangle entry << 12) | (count << 4)
   const float4* gridSph;  // per entry: the sphF / msphB entry
   const float2* gridSphX; // per entry: (16 r^2, list index bits), read when the cull passes
-  const uint32_t* gridTri;   // index into triF
+  const uint32_t* gridTri;   // index into triItem
   int gnx, gny, gnz;
   int nb_sph, nb_msph, nb_tri;   // the first nb_* entries of sphF / msphF+msphB / triF are too big for the grid: scanned linearly
   int grid_mode;          // 0: lists only; 1: waves too wide for the cone cull walk the grid; 2: every wave does
