@@ -961,6 +961,14 @@ __device__ __forceinline__ void scan_tile_list(const SceneDev& S, RayPack<R, NS>
   }
 }
 
+// (the LDS park of the level kernels, described at isect_setup below: words of slot r in the lane's own column)
+#define CFT_PARKED_WALK(LISTS, R) (((LISTS) & 2) != 0 && (R) > 1)   // which walk instances walk one-ray packs (scan_lists)
+template <int R, int NS> __device__ __forceinline__ void isect_park(const RayPack<R, NS>& P, float (*park)[CFT_BLOCK]);
+template <int NS> struct ParkLayout {
+  static constexpr int CAND = 3, WORD = 3 + 5 * NS, WORDS = (4 + 6 * NS) > 9 ? (3 + 6 * NS) : 9;
+};
+#define PARK(r, j) park[(r) * ParkLayout<NS>::WORDS + (j)][threadIdx.x]
+
 // f32 scan of every non-precise primitive for R rays (indices into [sphF | msph | triF | mtri]).
 // part / nparts (wave-uniform): this wave scans the part-th slice of each list (nparts = 1: all of it).
 // WCULL: try the wave-level cull first (the R-rays-per-lane kernels; every lane of the wave must be active).
@@ -970,7 +978,8 @@ __device__ __forceinline__ void scan_tile_list(const SceneDev& S, RayPack<R, NS>
 // tile >= 0 (level 0 of the default pipeline, with S.tile_off set): the wave's rays are pixels of that tile, and its
 // list stands for the static / moving spheres and static triangles.
 template <int R, int NS, bool WCULL = false, int LISTS = 3>
-__device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P, int part = 0, int nparts = 1, int tile = -1) {
+__device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P, int part = 0, int nparts = 1, int tile = -1,
+                                           float (*park)[CFT_BLOCK] = nullptr) {
   const int n4_all = (S.n_sphF + 3) >> 2;
   const int lo4 = n4_all * part / nparts, hi4 = n4_all * (part + 1) / nparts;
   Bundle B = {};
@@ -1017,6 +1026,56 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P,
       for (int s = 0; s < S.nb_item; ++s) scan_tri_item<R, NS>(S, P, tri_item(tp[3 * s], tp[3 * s + 1], tp[3 * s + 2]));
       scan_mtris<R, NS>(S, P, S.n_sphF + S.n_msph + S.n_triF, 0, 1);
     }
+    if constexpr ((LISTS & 8) != 0 && CFT_PARKED_WALK(LISTS, R)) {
+      // The walk instances of the level kernels (park given) walk their R slots one after the other, and a walk touches
+      // only its own slot's candidate set, bounds and motion words.  So those leave the registers here: the candidate
+      // sets go to the park now (where the epilogue wants them anyway), and each walk runs on a ONE-ray pack that
+      // takes its slot's set from the park and puts it back - 5 live candidate words instead of 5 R, and the slot's
+      // upper bound and margin recomputed from what the park and the pack hold (the R-ray pack kept all of that live
+      // across every walk: the walk instances sat at the 128-register cap, and what they spilled cost whole percents).
+      // Only the instances with triangle code walk this way (S20k -2.4 %); the sphere-only ones lost 2.8 % to it.
+      isect_park<R, NS>(P, park);
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (PK(P, thr4, r) < __builtin_inff()) {
+          if (fmaxf(fabsf(PK(P, o4x, r)), fmaxf(fabsf(PK(P, o4y, r)), fabsf(PK(P, o4z, r)))) > S.gfar4) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) PARK(r, ParkLayout<NS>::CAND + 5 * k + 2) = 0.0f;   // too far out for the walk's error bounds: lo3 = 0, rescan
+          } else {
+            RayPack<1, NS> Q;
+            Q.dx[0] = v2f{PK(P, dx, r), 0.f}; Q.dy[0] = v2f{PK(P, dy, r), 0.f}; Q.dz[0] = v2f{PK(P, dz, r), 1.f};
+            Q.o4x[0] = v2f{PK(P, o4x, r), 0.f}; Q.o4y[0] = v2f{PK(P, o4y, r), 0.f}; Q.o4z[0] = v2f{PK(P, o4z, r), 0.f};
+            Q.od2[0] = v2f{PK(P, od2, r), 0.f}; Q.thr4[0] = v2f{PK(P, thr4, r), __builtin_inff()};
+            {   // ray_setup's margin and upper bound again (same operations on the same numbers)
+              const float tx = 0.25f * PK(P, o4x, r), ty = 0.25f * PK(P, o4y, r), tz = 0.25f * PK(P, o4z, r);
+              const float dist = __builtin_amdgcn_sqrtf(fmaf(tz, tz, fmaf(ty, ty, tx * tx))) * 1.000001f + S.brad;
+              Q.negE16[0] = -16.0f * fmaf(dist, S.K1, S.K2);
+              const float u = (float)__hiloint2double(__float_as_int(PARK(r, 1)), __float_as_int(PARK(r, 0)));
+              Q.U[0] = (__float_as_int(PARK(r, 2)) >= 0) ? fmaf(fabsf(u), CFT_U4EPS, u) + 1e-30f : __builtin_inff();
+              if (NS == 2 && S.prec_motion) Q.U[0] = __builtin_inff();
+            }
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+              Q.word[k][0] = (LISTS & 1) ? __float_as_uint(PARK(r, ParkLayout<NS>::WORD + k)) : 0u;
+              Q.c[k][0].lo1 = PARK(r, ParkLayout<NS>::CAND + 5 * k + 0);
+              Q.c[k][0].lo2 = PARK(r, ParkLayout<NS>::CAND + 5 * k + 1);
+              Q.c[k][0].lo3 = PARK(r, ParkLayout<NS>::CAND + 5 * k + 2);
+              Q.c[k][0].i1 = __float_as_int(PARK(r, ParkLayout<NS>::CAND + 5 * k + 3));
+              Q.c[k][0].i2 = __float_as_int(PARK(r, ParkLayout<NS>::CAND + 5 * k + 4));
+            }
+            grid_walk_ray<1, NS, LISTS>(S, Q, 0);
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+              PARK(r, ParkLayout<NS>::CAND + 5 * k + 0) = Q.c[k][0].lo1;
+              PARK(r, ParkLayout<NS>::CAND + 5 * k + 1) = Q.c[k][0].lo2;
+              PARK(r, ParkLayout<NS>::CAND + 5 * k + 2) = Q.c[k][0].lo3;
+              PARK(r, ParkLayout<NS>::CAND + 5 * k + 3) = __int_as_float(Q.c[k][0].i1);
+              PARK(r, ParkLayout<NS>::CAND + 5 * k + 4) = __int_as_float(Q.c[k][0].i2);
+            }
+          }
+        }
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r)
       if (PK(P, thr4, r) < __builtin_inff()) {
@@ -1049,6 +1108,10 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P,
     c_f4p rp = AS_CONST(c_f4p, S.sphR2);
     v16f cur = sp[lo4];
     v4f cr = rp[lo4];
+    // (the first batch is waited for HERE: scalar loads return out of order, so the only wait there is is "all of them";
+    // left to the compiler it sits at the head of the loop, right behind the prefetch of the next batch - needed on the
+    // first trip only, paid on every one: the prefetch then covers nothing)
+    asm volatile("" : : "s"(cur[0]), "s"(cr[0]));
     for (int s4 = lo4; s4 < hi4; ++s4) {
       v16f nxt = sp[s4 + 1];
       v4f nr = rp[s4 + 1];
@@ -1090,6 +1153,7 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P,
     } else {
       c_f16p sp = AS_CONST(c_f16p, S.msphB);
       v16f cur = sp[mlo4];
+      asm volatile("" : : "s"(cur[0]));   // (as above)
       for (int s4 = mlo4; s4 < mhi4; ++s4) {
         v16f nxt = sp[s4 + 1];
         const int s = s4 << 2;
@@ -1592,10 +1656,6 @@ __device__ __forceinline__ f3 hit_normal(const SceneDev& S, int g, d3 p, uint32_
 // park dynamically - one copy of the f64 / shading code and its registers, not R.  Words of slot r:
 //   [0..2] precise-sphere hit (t lo, t hi, prim)   [3 + 5k ..] candidate set of scan k   [3 + 5 NS + k] motion word k
 // The fused kernel later reuses a slot's words for the surviving ray (9 words).
-template <int NS> struct ParkLayout {
-  static constexpr int CAND = 3, WORD = 3 + 5 * NS, WORDS = (4 + 6 * NS) > 9 ? (3 + 6 * NS) : 9;
-};
-#define PARK(r, j) park[(r) * ParkLayout<NS>::WORDS + (j)][threadIdx.x]
 
 // Before the scan: load the lane's R rays of this level (ray i, i + stride, ...), draw the motion words, test the
 // precise spheres, fill the pack.
@@ -2302,10 +2362,10 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(LevelArgs) {
         int tile = -1;   // level 0 of a tiled frame with per-tile lists: the trip's 64 R slots are pixels of one 32x8 tile
         if constexpr (GEN && (LISTS & 4) == 0 && 256 % (64 * R) == 0)
           if (S2.tile_off && A2.gen.tiled) tile = (int)((wb % (A2.gen.cam.width * A2.gen.cam.height)) >> 8);
-        scan_lists<R, NS, (LISTS & 4) == 0, (LISTS & 4) ? (LISTS | 8) : LISTS>(S2, P, 0, 1, tile);
+        scan_lists<R, NS, (LISTS & 4) == 0, (LISTS & 4) ? (LISTS | 8) : LISTS>(S2, P, 0, 1, tile, park);
       }
       CFT_STAMP(3);
-      isect_park<R, NS>(P, park);
+      if constexpr (!((LISTS & 4) != 0 && CFT_PARKED_WALK(LISTS, R))) isect_park<R, NS>(P, park);   // (those walk instances park on their way)
     }
     CFT_STAMP(4);
     uint32_t alive_bits = 0;
