@@ -47,6 +47,7 @@ struct Tri { Vec3 p0, p1, p2; };
 struct FlatShape {
   std::vector<std::pair<Vec3, double>> spheres;
   std::vector<Tri> tris;
+  bool or_pair = false;   // the two triangles are a Square::from_points: tri0.or(tri1) (object.rs:192)
 };
 struct Shape {
   virtual ~Shape() {}
@@ -70,7 +71,17 @@ struct Square : Shape {   // object.rs:147-162: x, y are not normalised here
     tri0 = {p0, p1, p2};
     tri1 = {p2, p3, p0};
   }
-  FlatShape flatten() const override { FlatShape f; f.tris = {tri0, tri1}; return f; }
+  bool or_pair = false;
+  // object.rs:169-174: tri0 = (p0, p1, p2), tri1 = (p1, p2, p3); hit_info is tri0.or(tri1) (object.rs:192), which for
+  // such a pair is NOT the closest of the two - flagged for the device (cftrt_scene_set_triangle_pairs)
+  static Square from_points(Vec3 p0, Vec3 p1, Vec3 p2, Vec3 p3) {
+    Square s({0, 0, 0}, {1, 0, 0}, {0, 1, 0}, 1.);
+    s.tri0 = {p0, p1, p2};
+    s.tri1 = {p1, p2, p3};
+    s.or_pair = true;
+    return s;
+  }
+  FlatShape flatten() const override { FlatShape f; f.tris = {tri0, tri1}; f.or_pair = or_pair; return f; }
 };
 struct Cube : Shape {   // object.rs:199-230
   Vec3 center, x, y; double len;
@@ -195,7 +206,8 @@ struct World {   // object.rs:305-356
   // Trait objects -> SoA primitive buffers + material table + light list, then cftrt_scene_commit.
   cftrt_scene* commit(Device& dev) const {
     std::vector<double> sc, sr, smv, t0, t1, t2, tmv, lsc, lsr, l0, l1, l2;
-    std::vector<int32_t> sobj, smat, tobj, tmat;
+    std::vector<int32_t> sobj, smat, tobj, tmat, tfirst, lfirst;
+    bool any_pair = false;
     std::vector<cftrt_material> mats;
     auto push3 = [](std::vector<double>& v, Vec3 p) { v.push_back(p.x); v.push_back(p.y); v.push_back(p.z); };
     for (size_t i = 0; i < objects.size(); ++i) {
@@ -203,7 +215,12 @@ struct World {   // object.rs:305-356
       mats.push_back(o.material);
       FlatShape f = o.shape->flatten();
       for (auto& s : f.spheres) { push3(sc, s.first); sr.push_back(s.second); push3(smv, o.moving_to); sobj.push_back((int32_t)i); smat.push_back((int32_t)i); }
-      for (auto& t : f.tris) { push3(t0, t.p0); push3(t1, t.p1); push3(t2, t.p2); push3(tmv, o.moving_to); tobj.push_back((int32_t)i); tmat.push_back((int32_t)i); }
+      for (size_t j = 0; j < f.tris.size(); ++j) {
+        const Tri& t = f.tris[j];
+        tfirst.push_back(f.or_pair && j == 1 ? (int32_t)tobj.size() - 1 : -1);
+        push3(t0, t.p0); push3(t1, t.p1); push3(t2, t.p2); push3(tmv, o.moving_to); tobj.push_back((int32_t)i); tmat.push_back((int32_t)i);
+      }
+      any_pair = any_pair || f.or_pair;
     }
     std::vector<cftrt_light> lrows;
     for (const Light& l : lights) {
@@ -216,7 +233,12 @@ struct World {   // object.rs:305-356
         r.sph_begin = (int32_t)lsr.size(); r.sph_count = (int32_t)f.spheres.size();
         r.tri_begin = (int32_t)(l0.size() / 3); r.tri_count = (int32_t)f.tris.size();
         for (auto& s : f.spheres) { push3(lsc, s.first); lsr.push_back(s.second); }
-        for (auto& t : f.tris) { push3(l0, t.p0); push3(l1, t.p1); push3(l2, t.p2); }
+        for (size_t j = 0; j < f.tris.size(); ++j) {
+          const Tri& t = f.tris[j];
+          lfirst.push_back(f.or_pair && j == 1 ? (int32_t)(l0.size() / 3) - 1 : -1);
+          push3(l0, t.p0); push3(l1, t.p1); push3(l2, t.p2);
+        }
+        any_pair = any_pair || f.or_pair;
       }
       lrows.push_back(r);
     }
@@ -228,6 +250,8 @@ struct World {   // object.rs:305-356
       dev.check(cftrt_scene_set_materials(s, mats.data(), (int64_t)mats.size()));
       dev.check(cftrt_scene_set_lights(s, lrows.data(), (int64_t)lrows.size(), lsc.data(), lsr.data(), (int64_t)lsr.size(),
                                        l0.data(), l1.data(), l2.data(), (int64_t)(l0.size() / 3)));
+      if (any_pair)
+        dev.check(cftrt_scene_set_triangle_pairs(s, tfirst.data(), (int64_t)tfirst.size(), lfirst.data(), (int64_t)lfirst.size()));
       dev.check(cftrt_scene_commit(s));
     } catch (...) {
       cftrt_scene_destroy(s);

@@ -1092,8 +1092,7 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
 #undef CFT_TAIL
     return;
   }
-  static const uint32_t blocks_per_cu = getenv("CFTRT_BLOCKS_PER_CU") ? (uint32_t)atoi(getenv("CFTRT_BLOCKS_PER_CU")) : 8u;   // (experiments)
-  const uint32_t g = grid_for(ctx, ((uint64_t)P + R - 1) / R, blocks_per_cu);
+  const uint32_t g = grid_for(ctx, ((uint64_t)P + R - 1) / R, 8u);   // 8 blocks a CU (4 and 16/32 measured slower, r03)
   const GenArgs no_gen{};
   // (experiments: unused dynamic LDS per block lowers the number of resident blocks per CU)
   static const uint32_t dyn_lds = getenv("CFTRT_EXTRA_LDS") ? (uint32_t)atoi(getenv("CFTRT_EXTRA_LDS")) : 0u;

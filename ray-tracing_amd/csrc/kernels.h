@@ -796,13 +796,7 @@ __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>&
 #endif
         const uint32_t e = e0 + (uint32_t)__builtin_ctz(pass);
         pass &= pass - 1u;
-#ifdef CFT_X4
-        float4 a = a4[0];
-#pragma unroll
-        for (int j = 1; j < CFT_WALK_BATCH; ++j) if (e - e0 == (uint32_t)j) a = a4[j];
-#else
         const float4 a = S.gridSph[e];    // (again: the batch sits in registers under a constant index only)
-#endif
         const float2 b = S.gridSphX[e];   // (16 r^2, list index)
         const int idx = __float_as_int(b.y);
         bool seen = true;
@@ -1313,11 +1307,7 @@ __device__ __forceinline__ Winner ray_epilogue_w(const SceneDev& S, float ox, fl
   // scan happened to rank first (the per-tile lists are filled through atomics, in no fixed order).
   auto wins_tie = [&](const Winner& w, const Winner& cur) {
     const int a = w.obj, b = obj_of(cur);
-#ifdef CFT_OLD_TIE
-    return a < b;
-#else
     return a < b || (a == b && w.g < cur.g);
-#endif
   };
   if (c.i1 >= 0) {
     Winner w;
@@ -2400,13 +2390,11 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(LevelArgs) {
         hit.b0 = hit.a0;
         double tb = hit.ta;
         if (NS == 2) isect_hit<NS>(S, live, r, 1, a.x, a.y, a.z, a.w, b.x, b.y, park, A.stats, &hit.b0, &hit.b1, &tb, &hit.mat_id);
-#ifndef CFT_NO_DBG
         if (A.dbg_t != nullptr && live) {   // (wave-uniform pointer test; never taken in a render call)
           const size_t w0 = (size_t)NS * __float_as_uint(c.y);
           A.dbg_t[w0] = hit.ta; A.dbg_prim[w0] = __float_as_int(hit.a0.y);
           if (NS == 2) { A.dbg_t[w0 + 1] = tb; A.dbg_prim[w0 + 1] = __float_as_int(hit.b0.y); }
         }
-#endif
         CFT_STAMP(4);   // (diagnostic build: "park" = the exact evaluation and hit record of the slots; "epilogue" = shading)
         f3 thr = mk3(b.z, b.w, c.x), npos, ndir;
         const bool alive = live && shade_one(S, hit, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), &thr, __float_as_uint(c.y), A.level,

@@ -27,6 +27,10 @@ use std::ffi::CStr;
 pub enum GpuShape {
     Sphere { center: Vec3, radius: f64 },
     Triangles(Vec<[Vec3; 3]>),
+    /// The two triangles of a `Square::from_points` (`object.rs:169-174`): `hit_info` is `tri0.or(tri1)`
+    /// (`object.rs:192`), so the second counts only where the first is not hit - flagged for the device with
+    /// `cftrt_scene_set_triangle_pairs` (a `Square::new` is planar and shares only its diagonal: plain `Triangles`).
+    OrPair([[Vec3; 3]; 2]),
 }
 
 // ---- the three defaulted trait methods (added to the trait definitions in object.rs:13, material.rs:12, light.rs:7)
@@ -54,17 +58,18 @@ impl Triangle {
 }
 impl Square {
     pub(crate) fn gpu_desc_impl(&self) -> Option<GpuShape> {
-        // Only planar squares: hit_info returns tri0's hit even if tri1's is nearer (object.rs:190-196), which the
-        // device's closest-of-all rule reproduces exactly when both triangles lie in one plane (every Square::new).
-        let n0 = self.tri0.normal();
-        let n1 = self.tri1.normal();
-        if (n0.cross(n1)).len() > 1e-9 {
-            return None;
+        // hit_info returns tri0's hit even where tri1's is nearer (object.rs:190-196).  For a Square::new - tri1 =
+        // (tri0.p2, p3, tri0.p0) in tri0's plane - that is the closest of the two, the device's ordinary rule; anything
+        // else (from_points: tri1 = (p1, p2, p3), overlapping or out of plane) goes as a flagged pair.
+        let t0 = [self.tri0.p0, self.tri0.p1, self.tri0.p2];
+        let t1 = [self.tri1.p0, self.tri1.p1, self.tri1.p2];
+        let coplanar = (self.tri0.normal().cross(self.tri1.normal())).len() <= 1e-9;
+        let shares_diagonal = (self.tri1.p0 - self.tri0.p2).len() == 0.0 && (self.tri1.p2 - self.tri0.p0).len() == 0.0;
+        if coplanar && shares_diagonal {
+            Some(GpuShape::Triangles(vec![t0, t1]))
+        } else {
+            Some(GpuShape::OrPair([t0, t1]))
         }
-        Some(GpuShape::Triangles(vec![
-            [self.tri0.p0, self.tri0.p1, self.tri0.p2],
-            [self.tri1.p0, self.tri1.p1, self.tri1.p2],
-        ]))
     }
 }
 impl Cube {
@@ -153,6 +158,8 @@ pub struct FlatWorld {
     pub tri_moving: Vec<f64>,
     pub tri_obj: Vec<i32>,
     pub tri_mat: Vec<i32>,
+    pub tri_first: Vec<i32>,  // per triangle: i - 1 for the second triangle of a Square::from_points, else -1
+    pub ltri_first: Vec<i32>, // the same over the light-shape triangles
     pub materials: Vec<cftrt_material>,
     pub lights: Vec<cftrt_light>,
     pub lsph_center: Vec<f64>,
@@ -167,7 +174,7 @@ fn push3(dst: &mut Vec<f64>, v: Vec3) {
 }
 
 impl World {
-    /// `None` as soon as one shape, material or light has no device form (a user impl, a non-planar square).
+    /// `None` as soon as one shape, material or light has no device form (a user impl).
     pub fn flatten(&self) -> Option<FlatWorld> {
         let mut f = FlatWorld::default();
         for (i, obj) in self.objects.iter().enumerate() {
@@ -183,8 +190,14 @@ impl World {
                     f.sph_obj.push(i as i32);
                     f.sph_mat.push(mat_id);
                 }
-                GpuShape::Triangles(tris) => {
-                    for t in tris {
+                shape @ GpuShape::Triangles(_) | shape @ GpuShape::OrPair(_) => {
+                    let (tris, pair) = match shape {
+                        GpuShape::Triangles(t) => (t, false),
+                        GpuShape::OrPair(t) => (t.to_vec(), true),
+                        _ => unreachable!(),
+                    };
+                    for (j, t) in tris.into_iter().enumerate() {
+                        f.tri_first.push(if pair && j == 1 { f.tri_obj.len() as i32 - 1 } else { -1 });
                         push3(&mut f.tri_p0, t[0]);
                         push3(&mut f.tri_p1, t[1]);
                         push3(&mut f.tri_p2, t[2]);
@@ -205,10 +218,16 @@ impl World {
                     push3(&mut f.lsph_center, center);
                     f.lsph_radius.push(radius);
                 }
-                Some(GpuShape::Triangles(tris)) => {
+                Some(shape @ GpuShape::Triangles(_)) | Some(shape @ GpuShape::OrPair(_)) => {
+                    let (tris, pair) = match shape {
+                        GpuShape::Triangles(t) => (t, false),
+                        GpuShape::OrPair(t) => (t.to_vec(), true),
+                        _ => unreachable!(),
+                    };
                     row.tri_begin = (f.ltri_p0.len() / 3) as i32;
                     row.tri_count = tris.len() as i32;
-                    for t in tris {
+                    for (j, t) in tris.into_iter().enumerate() {
+                        f.ltri_first.push(if pair && j == 1 { (f.ltri_p0.len() / 3) as i32 - 1 } else { -1 });
                         push3(&mut f.ltri_p0, t[0]);
                         push3(&mut f.ltri_p1, t[1]);
                         push3(&mut f.ltri_p2, t[2]);
@@ -276,6 +295,10 @@ impl GpuScene {
                 ptr_or_null(&flat.lsph_center), ptr_or_null(&flat.lsph_radius), flat.lsph_radius.len() as i64,
                 ptr_or_null(&flat.ltri_p0), ptr_or_null(&flat.ltri_p1), ptr_or_null(&flat.ltri_p2),
                 (flat.ltri_p0.len() / 3) as i64))?;
+            if flat.tri_first.iter().chain(flat.ltri_first.iter()).any(|&x| x >= 0) {
+                check(g.ctx, cftrt_scene_set_triangle_pairs(g.scene, ptr_or_null(&flat.tri_first), flat.tri_first.len() as i64,
+                    ptr_or_null(&flat.ltri_first), flat.ltri_first.len() as i64))?;
+            }
             check(g.ctx, cftrt_scene_commit(g.scene))?;
             Ok(g)
         }
@@ -366,44 +389,74 @@ impl World {
         let mut id = [0u8; CFTRT_COMM_ID_BYTES];
         unsafe { check(std::ptr::null(), cftrt_comm_unique_id(id.as_mut_ptr()))? };
         let mut out = vec![0f32; n_floats];
-        let results: Vec<Result<usize, GpuError>> = std::thread::scope(|s| {
+        // Phase 1, every GPU: upload the scene and take the image buffer.  Only when ALL of them succeeded does any rank
+        // enter the communicator: a rank that failed here would leave the others waiting in ncclCommInitRank for ever.
+        let setups: Vec<Result<(GpuScene, usize), GpuError>> = std::thread::scope(|s| {
             let handles: Vec<_> = (0..n_gpus)
                 .map(|g| {
-                    let (flat, cam, id, alloc, free) = (&flat, &cam, &id, &alloc, &free);
-                    s.spawn(move || -> Result<usize, GpuError> {
+                    let (flat, alloc) = (&flat, &alloc);
+                    s.spawn(move || -> Result<(GpuScene, usize), GpuError> {
                         let sc = GpuScene::upload(flat, g)?;
                         let buf = alloc(g, n_floats * 4); // zero-filled device memory on GPU g
-                        let (b, e) = (spp * g as u32 / n_gpus as u32, spp * (g as u32 + 1) / n_gpus as u32);
-                        let r = unsafe {
-                            check(sc.ctx, cftrt_comm_init(sc.ctx, n_gpus, g, id.as_ptr()))
-                                .and_then(|_| check(sc.ctx, cftrt_render_device(sc.scene, cam, width as u32, height as u32,
-                                    b, e, depth as u32, seed, buf, std::ptr::null_mut())))
-                                .and_then(|_| check(sc.ctx, cftrt_reduce(sc.ctx, buf, n_floats as u64, 0)))
-                                .and_then(|_| check(sc.ctx, cftrt_comm_destroy(sc.ctx)))
-                        };
-                        if g != 0 || r.is_err() {
-                            free(g, buf);
-                            return r.map(|_| 0usize);
+                        if buf.is_null() {
+                            return Err(GpuError { code: CFTRT_ERR_HIP, text: format!("device image allocation failed on GPU {}", g) });
                         }
-                        Ok(buf as usize) // GPU 0 keeps the sum for the download below
+                        Ok((sc, buf as usize))
                     })
                 })
                 .collect();
             handles.into_iter().map(|h| h.join().unwrap()).collect()
         });
-        let mut root = 0usize;
-        for (g, r) in results.into_iter().enumerate() {
-            let v = r?;
-            if g == 0 {
-                root = v;
+        let release = |ranks: &[(GpuScene, usize)]| {
+            for (g, (_, buf)) in ranks.iter().enumerate() {
+                free(g as i32, *buf as *mut std::os::raw::c_void);
+            }
+        };
+        let mut ranks: Vec<(GpuScene, usize)> = Vec::new();
+        let mut first_err = None;
+        for r in setups {
+            match r {
+                Ok(x) => ranks.push(x),
+                Err(e) => { if first_err.is_none() { first_err = Some(e); } }
             }
         }
+        if let Some(e) = first_err {
+            release(&ranks); // (buffers of the ranks that did come up; their GpuScene drops free ctx and scene)
+            return Err(e);
+        }
+        // Phase 2, every GPU: communicator, render, reduce into GPU 0's image.
+        let results: Vec<Result<(), GpuError>> = std::thread::scope(|s| {
+            let handles: Vec<_> = ranks
+                .iter()
+                .enumerate()
+                .map(|(g, (sc, buf))| {
+                    let (cam, id) = (&cam, &id);
+                    let (g, buf) = (g as i32, *buf as *mut std::os::raw::c_void);
+                    s.spawn(move || -> Result<(), GpuError> {
+                        let (b, e) = (spp * g as u32 / n_gpus as u32, spp * (g as u32 + 1) / n_gpus as u32);
+                        unsafe {
+                            check(sc.ctx, cftrt_comm_init(sc.ctx, n_gpus, g, id.as_ptr()))?;
+                            // from here on every rank makes the same collective calls, whatever its own render returned
+                            let r = check(sc.ctx, cftrt_render_device(sc.scene, cam, width as u32, height as u32, b, e,
+                                                                      depth as u32, seed, buf, std::ptr::null_mut()));
+                            let red = check(sc.ctx, cftrt_reduce(sc.ctx, buf, n_floats as u64, 0));
+                            let _ = cftrt_comm_destroy(sc.ctx);
+                            r.and(red)
+                        }
+                    })
+                })
+                .collect();
+            handles.into_iter().map(|h| h.join().unwrap()).collect()
+        });
+        if let Some(e) = results.into_iter().find_map(|r| r.err()) {
+            release(&ranks);
+            return Err(e);
+        }
+        let root = ranks[0].1;
         download(0, root as *mut std::os::raw::c_void, &mut out);
-        free(0, root as *mut std::os::raw::c_void);
+        release(&ranks);
         Ok(Some(out.chunks(3).map(|c| Vec3::new(c[0] as f64, c[1] as f64, c[2] as f64)).collect()))
     }
 }
 
-// examples/scene.rs then reads
-//     let raw = world.render(&camera, WIDTH, HEIGHT, TRACE_DEPTH);
-// followed by its existing `/ SAMPLE_RATE`, `vec3_to_rgb`, `img.save` (scene.rs:111-119).
+// The two examples rewritten to the one call: rust/examples/scene.rs and rust/examples/cornell.rs (text, unverified).

@@ -3,7 +3,7 @@
 #   bash scripts/profile_round.sh r02     -> gpurun_out/prof_r02/*  (copy what is to be judged into profiles/ as r02_*)
 # Kernel trace and counters are separate runs; each --pmc pass is its own run within the per-block counter limits.
 set -e
-tag=$1
+tag=$1; shift || true
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/prof_$tag
 mkdir -p $out
@@ -18,6 +18,22 @@ PMC_WARMUP=1 bash scripts/pmc_pass.sh ${tag}_lds 0 SQ_INSTS_LDS SQ_ACTIVE_INST_L
 PMC_WARMUP=1 bash scripts/pmc_pass.sh ${tag}_tcp 0 TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE
 PMC_WARMUP=1 bash scripts/pmc_pass.sh ${tag}_fetch 0 FETCH_SIZE
 PMC_WARMUP=1 bash scripts/pmc_pass.sh ${tag}_write 0 WRITE_SIZE
+# the L2's fabric-side requests behind FETCH_SIZE / WRITE_SIZE, per dispatch (4 TCC counters a pass)
+PMC_WARMUP=1 bash scripts/pmc_pass.sh ${tag}_tcc_rd 0 TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum
+PMC_WARMUP=1 bash scripts/pmc_pass.sh ${tag}_tcc_wr 0 TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_REQ_sum TCC_READ_sum
+cp gpurun_out/pmc_${tag}_tcc_rd.json $out/pmc_tcc_read.json
+cp gpurun_out/pmc_${tag}_tcc_wr.json $out/pmc_tcc_write.json
+# the plain linear scan (what roofline.frac is measured on): SQ counters per level
+( export CFTRT_GRID=0 CFTRT_WAVE_CULL=0 CFTRT_TILE_LISTS=0
+  PMC_WARMUP=1 bash scripts/pmc_pass.sh ${tag}_sq_plain 0 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE )
+cp gpurun_out/pmc_${tag}_sq_plain.json $out/pmc_sq_plain_scan.json
+python3 scripts/pmc_levels.py gpurun_out/pmc_${tag}_sq_plain > $out/pmc_sq_plain_scan_levels.txt
+python3 scripts/pmc_levels.py gpurun_out/pmc_${tag}_sq > $out/pmc_sq_levels.txt
+# which sources the counters describe (bench.py compares it with the tree it runs from)
+python3 -c "
+import sys; sys.path.insert(0, '.')
+import bench, json
+json.dump({'kernel_source_sha256_16': bench.kernel_source_hash()}, open('$out/pmc_sq.meta.json', 'w'))"
 rays=$(python3 -c "import json;print(json.load(open('$out/bench_under_rocprof.json'))['config']['rays_per_step_per_gpu'])")
 python3 scripts/hbm_traffic.py gpurun_out/pmc_${tag}_fetch gpurun_out/pmc_${tag}_write $rays $out/hbm_traffic.json > /dev/null
 cp gpurun_out/pmc_${tag}_sq.json $out/pmc_sq.json

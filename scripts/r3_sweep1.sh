@@ -12,7 +12,6 @@ for l in sys.stdin:
 echo "== baseline"; run "C3 C5 C2 C1" || exit 1
 echo "== baseline again"; run "C3" || exit 1
 for v in 2 3; do echo "== VARIANT=$v"; CFTRT_VARIANT=$v run "C3 C5" || exit 1; done
-for b in 4 16 32; do echo "== BLOCKS_PER_CU=$b"; CFTRT_BLOCKS_PER_CU=$b run "C3 C5" || exit 1; done
 for f in "1,2097152" "1,524288" "1,262144"; do echo "== FINISH=$f"; CFTRT_FINISH=$f run "C3" || exit 1; done
 echo "== X4 lib"; CFTRT_LIB=$PWD/ray-tracing_amd/csrc/libcftrt_x4.so run "C3 C5" || exit 1
 echo "== base lib"; run "C3 C5" || exit 1

@@ -148,3 +148,21 @@ def test_square_from_points_flattens_as_a_pair(rt, orc):
     ray2 = np.array([[3.0, 3.0, 0.5, -r, -r, 0.0]])
     ids, t, _, pt2, _ = ow.hit(ray2)
     assert ids[0] == 1 and np.allclose(pt2[0], (0.75, 0.75, 0.5))
+
+
+def test_comm_entry_points_reject_bad_arguments_from_many_threads(rt):
+    """No GPU here: the multi-GPU entry points still return codes (never crash) when eight threads hit them at once -
+    the first call loads RCCL behind a function-local static, so its initialisation is what races."""
+    import threading
+    L = rt.load()
+    out = []
+
+    def work():
+        buf = (C.c_ubyte * 128)()
+        out.append((L.cftrt_comm_unique_id(None), L.cftrt_comm_init(None, 2, 0, buf), L.cftrt_reduce(None, None, 0, 0),
+                    L.cftrt_comm_destroy(None), L.cftrt_comm_unique_id(buf) in (0, 2)))
+
+    ts = [threading.Thread(target=work) for _ in range(8)]
+    [t.start() for t in ts]
+    [t.join(timeout=60) for t in ts]
+    assert out == [(1, 1, 1, 1, True)] * 8

@@ -42,3 +42,24 @@ def test_checker_notices_drift(tmp_path):
         p.write_text(text.replace(old, new))
         r = _run(os.path.join(ROOT, "include", "cftrt.h"), str(p))
         assert r.returncode == 1 and "MISMATCH" in r.stdout, (old, r.stdout)
+
+
+def test_facade_and_examples_use_declared_names_only():
+    """rust/facade/gpu.rs and rust/examples/*.rs are text too: every cftrt_* / CFTRT_* name they use must be one the FFI
+    crate declares (a function, a struct or a constant), and every World method the example text calls must be one the
+    façade defines."""
+    decl = open(RS).read()
+    declared = set(re.findall(r"pub fn (cftrt_\w+)", decl)) | set(re.findall(r"pub struct (cftrt_\w+)", decl)) | \
+        set(re.findall(r"pub const (CFTRT_\w+)", decl))
+    facade = open(os.path.join(ROOT, "rust", "facade", "gpu.rs")).read()
+    files = [os.path.join(ROOT, "rust", "facade", "gpu.rs")]
+    exdir = os.path.join(ROOT, "rust", "examples")
+    files += [os.path.join(exdir, f) for f in sorted(os.listdir(exdir)) if f.endswith(".rs")]
+    assert len(files) >= 2
+    for f in files:
+        code = re.sub(r"//.*", "", open(f).read())
+        used = set(re.findall(r"\b(cftrt_\w+|CFTRT_\w+)\b", code)) - {"cftrt_sys"}   # (the crate's own name)
+        assert used <= declared, (f, sorted(used - declared))
+        if "examples" in f:
+            for m in set(re.findall(r"world\.(\w+)\(", code)):
+                assert re.search(r"pub fn %s\b" % m, facade), (f, m)

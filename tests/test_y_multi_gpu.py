@@ -67,3 +67,48 @@ def test_c_abi_reduce_world_size_one(rt):
     assert np.array_equal(acc.numpy(), before)
     dev.comm_destroy()
     dev.close()
+
+
+def test_comm_calls_from_two_threads(rt):
+    """cftrt.h invites one host thread per GPU: two threads, each with its OWN ctx (both on the one card here), go
+    through cftrt_comm_unique_id / cftrt_comm_init / cftrt_reduce / cftrt_comm_destroy at the same time - the first use
+    of RCCL (a dlopen behind a function-local static) races between them - each as a communicator of one rank, plus the
+    argument and state errors.  Every call returns its code; nothing hangs or crashes."""
+    import threading
+    results, errors = {}, []
+    start = threading.Barrier(2)
+
+    def work(k):
+        try:
+            dev = rt.Device(0)
+            acc = hm.DeviceArray(1024)
+            start.wait(timeout=60)
+            codes = []
+            try:
+                dev.reduce(acc.data_ptr(), 1024, 0)
+            except rt.CftrtError as e:
+                codes.append(e.code)                             # 3: no communicator yet
+            uid = dev.comm_unique_id()
+            for bad in ((0, 0), (1, 1), (1, -1)):                # size 0, rank = size, negative rank
+                try:
+                    dev.comm_init(bad[0], bad[1], uid)
+                except rt.CftrtError as e:
+                    codes.append(e.code)                         # 1 each
+            dev.comm_init(1, 0, uid)
+            try:
+                dev.comm_init(1, 0, uid)
+            except rt.CftrtError as e:
+                codes.append(e.code)                             # 3: already has one
+            dev.reduce(acc.data_ptr(), 1024, 0)
+            dev.comm_destroy()
+            dev.comm_destroy()                                   # idempotent
+            dev.close()
+            results[k] = codes
+        except Exception as e:                                   # noqa: BLE001 - reported below
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in ts]
+    [t.join(timeout=120) for t in ts]
+    assert not errors, errors
+    assert results == {0: [3, 1, 1, 1, 3], 1: [3, 1, 1, 1, 3]}
