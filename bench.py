@@ -329,6 +329,7 @@ def main():
                                    + (f"{spp} spp per GPU (weak)" if args.scaling == "weak" else f"{spp} spp split over the GPUs (strong)")
                                    + "; sample-range split, RCCL reduce of the f32 image",
                        "rays_per_step_per_gpu": int(s0.rays), "paths_per_step_per_gpu": int(s0.paths),
+                       "rays_level1_per_gpu": int(s0.rays_per_level[1]),
                        "trace_levels": int(s0.levels), "exact_second_evals": int(s0.exact_second),
                        "exact_rescans": int(s0.exact_rescan)},
             "roofline": roof,

@@ -8,6 +8,9 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 
+full, order = {}, defaultdict(list)
+
+
 def per_kernel(d, counter):
     f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
     rows = defaultdict(list)   # base kernel name -> [(dispatch id, value)]
@@ -19,8 +22,10 @@ def per_kernel(d, counter):
         k = int(r["Dispatch_Id"])
         acc[k] += float(r["Counter_Value"])
         name[k] = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+        full[k] = r["Kernel_Name"].split("(")[0].replace("void ", "")
     for k in sorted(acc):
         rows[name[k]].append(acc[k])
+        order[counter].append((full[k], acc[k]))
     return rows
 
 
@@ -42,5 +47,24 @@ for k in fetch:
                          "bytes_per_ray": (fb + wb) / rays,
                          "largest_launch_fetch_bytes_corrected": 2.0 * 1024.0 * max(half_f),
                          "largest_launch_write_bytes": 1024.0 * max(half_w) if half_w else 0.0}
+# the level launches of the last frame one by one (the two passes dispatch the same sequence): the level-0 launch is
+# the instance that generates (<..., true>); its own algorithmic bytes are stated beside the counters
+lv_f = [x for x in order["FETCH_SIZE"] if x[0].startswith("k_trace_level")]
+lv_w = [x for x in order["WRITE_SIZE"] if x[0].startswith("k_trace_level")]
+lv_f, lv_w = lv_f[len(lv_f) // 2:], lv_w[len(lv_w) // 2:]
+out["level_launches"] = [{"level": i, "kernel": f[0], "fetch_bytes_corrected": 2.0 * 1024.0 * f[1], "write_bytes": 1024.0 * w[1]}
+                         for i, (f, w) in enumerate(zip(lv_f, lv_w))]
+if len(sys.argv) > 6:   # PATHS_PER_STEP LEVEL1_RAYS: what level 0 has to move by itself
+    paths, l1 = int(sys.argv[5]), int(sys.argv[6])
+    l0 = out["level_launches"][0]
+    own = {"reads: its generated rays back from the queue, 24 B each (16 + 8)": 24.0 * paths,
+           "writes: its generated rays into the queue, 24 B each": 24.0 * paths,
+           "writes: survivors into the next level's queue, 40 B each": 40.0 * l1,
+           "writes: radiance of the paths that end here, 12 B each": 12.0 * (paths - l1)}
+    rd = sum(v for k, v in own.items() if k.startswith("reads"))
+    wr = sum(v for k, v in own.items() if k.startswith("writes"))
+    out["level0_accounting"] = {"paths": paths, "level1_rays": l1, "algorithmic_bytes": own,
+                                "fetch_over_own_reads": l0["fetch_bytes_corrected"] / rd,
+                                "write_over_own_writes": l0["write_bytes"] / wr}
 json.dump(out, open(sys.argv[4], "w"), indent=1)
 print(json.dumps(out, indent=1))

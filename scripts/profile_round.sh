@@ -35,7 +35,9 @@ import sys; sys.path.insert(0, '.')
 import bench, json
 json.dump({'kernel_source_sha256_16': bench.kernel_source_hash()}, open('$out/pmc_sq.meta.json', 'w'))"
 rays=$(python3 -c "import json;print(json.load(open('$out/bench_under_rocprof.json'))['config']['rays_per_step_per_gpu'])")
-python3 scripts/hbm_traffic.py gpurun_out/pmc_${tag}_fetch gpurun_out/pmc_${tag}_write $rays $out/hbm_traffic.json > /dev/null
+paths=$(python3 -c "import json;print(json.load(open('$out/bench_under_rocprof.json'))['config']['paths_per_step_per_gpu'])")
+l1=$(python3 -c "import json;print(json.load(open('$out/bench_under_rocprof.json'))['config']['rays_level1_per_gpu'])")
+python3 scripts/hbm_traffic.py gpurun_out/pmc_${tag}_fetch gpurun_out/pmc_${tag}_write $rays $out/hbm_traffic.json $paths $l1 > /dev/null
 cp gpurun_out/pmc_${tag}_sq.json $out/pmc_sq.json
 cp gpurun_out/pmc_${tag}_lds.json $out/pmc_lds_occupancy.json
 cp gpurun_out/pmc_${tag}_tcp.json $out/pmc_ta_tcp.json
@@ -49,4 +51,9 @@ bash scripts/trace_config.sh ${tag}_c5 C5 > $out/c5_level_times.txt
 bash scripts/pmc_config.sh ${tag}_c5_sq C5 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
 cp gpurun_out/pmc_${tag}_c5_sq.json $out/pmc_sq_c5_s20k.json
 python3 scripts/bench_configs.py C1 C2 C2p C3 C5 C4 > $out/configs.jsonl
+# one rank's share of the strong-scaling frame (64 spp split over N), and the timeline of the N = 8 share
+python3 scripts/strong_share.py > $out/strong_share.txt
+mkdir -p $out/tl8
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out/tl8 -o p -- python3 scripts/strong_share.py 8 > /dev/null 2>&1
+python3 scripts/timeline.py $out/tl8 > $out/strong_share_n8_timeline.txt
 ls -la $out

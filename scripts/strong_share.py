@@ -4,10 +4,14 @@ import importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 rt = importlib.import_module("ray-tracing_amd")
+if os.environ.get("CFTRT_FINISH"):        # "on[,below]"
+    f = os.environ["CFTRT_FINISH"].split(",")
+    rt.default_device().set_finish(int(f[0]), int(f[1]) if len(f) > 1 else 0)
 w, c = rt.scenes.s500()
 c = c.with_sample_rate(64)
 w.render(c, 1920, 1080, 50, spp_begin=0, spp_end=2)
-for n in (1, 2, 4, 8):
+ns = [int(x) for x in sys.argv[1:]] or [1, 2, 4, 8]   # (one N: for a kernel trace of that share)
+for n in ns:
     b, e = rt.multi.sample_range(64, n, 0)
     best = None
     for _ in range(5):
