@@ -697,12 +697,20 @@ __device__ __forceinline__ void scan_msphere(const SceneDev& S, RayPack<R, NS>& 
 //    (ray_epilogue) - the stop needs no trust in the certificate.
 // Rays that start farther than 256 E from the scene centre are not walked: in the level kernels they go to the exact
 // f64 rescan (lo3 = 0), in the one-ray form closest_hit the wave scans the lists.
+#ifndef CFT_WALK_ALWAYS
+#define CFT_WALK_ALWAYS 2
+#endif
+#ifndef CFT_WALK_BATCH_PARKED
+#define CFT_WALK_BATCH_PARKED 4
+#endif
 #ifndef CFT_WALK_BATCH
 #define CFT_WALK_BATCH 2   // sphere entries of a cell tested per round of loads (measured: 2 beats 1 and 4 on S500 and S20k)
 #endif
 template <int R, int NS, int LISTS>
 __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>& P, int r) {
   const float inf = __builtin_inff();
+  // entries per round of loads: a one-ray pack (the instances that park the others) leaves registers for more
+  constexpr int NB = R == 1 ? CFT_WALK_BATCH_PARKED : CFT_WALK_BATCH;
   const float dx = PK(P, dx, r), dy = PK(P, dy, r), dz = PK(P, dz, r);
   const float ox = 0.25f * PK(P, o4x, r), oy = 0.25f * PK(P, o4y, r), oz = 0.25f * PK(P, o4z, r);
   // reciprocals that stay finite (a zero component never reaches a plane: |t| ~ 1e30 * distance)
@@ -764,20 +772,26 @@ __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>&
     uint2 next = make_uint2(0u, 0u);
     if (inside && tnr <= tendr)
       next = cells[__umul24(__umul24((uint32_t)cz, (uint32_t)S.gny) + (uint32_t)cy, (uint32_t)S.gnx) + (uint32_t)cx];
-    // The cell's sphere entries, CFT_WALK_BATCH at a time: the 16 B loads of a batch are in flight together (one after
+    // The cell's sphere entries, NB at a time: the 16 B loads of a batch are in flight together (one after
     // the other they are a chain of dependent round trips: a cell of a 20 k-primitive scene holds up to 19 entries),
     // the cull of each is 8 FMAs, and only entries that pass go on to the (rare, divergent) candidate path.  A cell
     // visited holds 1.3 (S500) to 2.2 (S20k) entries on average: batches of 4 mostly test clamped repeats.
-    for (uint32_t e0 = cell.x >> 8, ee = (cell.x >> 8) + (cell.x & 255u); e0 < ee; e0 += (uint32_t)CFT_WALK_BATCH) {
-      float4 a4[CFT_WALK_BATCH];
+    for (uint32_t e0 = cell.x >> 8, ee = (cell.x >> 8) + (cell.x & 255u); e0 < ee; e0 += (uint32_t)NB) {
+      float4 a4[NB];
 #ifdef CFT_STAMPS
       wk_batches += 1; wk_xbatch += CFT_WK_LEADER() ? 1u : 0u;
 #endif
 #pragma unroll
-      for (int j = 0; j < CFT_WALK_BATCH; ++j) a4[j] = S.gridSph[min(e0 + (uint32_t)j, ee - 1u)];
+      for (int j = 0; j < NB; ++j) {
+        // the first two of a batch are loaded whatever the cell holds (clamped repeats); the others only by lanes whose
+        // cell has that many entries left (a divergent load costs the texture path by its active lanes)
+        if (j < CFT_WALK_ALWAYS) a4[j] = S.gridSph[min(e0 + (uint32_t)j, ee - 1u)];
+        else if (e0 + (uint32_t)j < ee) a4[j] = S.gridSph[e0 + (uint32_t)j];
+        else a4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
       uint32_t pass = 0u;
 #pragma unroll
-      for (int j = 0; j < CFT_WALK_BATCH; ++j) {
+      for (int j = 0; j < NB; ++j) {
         // the per-ray cull of scan_sphere, unpacked (same operations in the same order): q = 2 oc.d, pass iff the
         // LINE meets the sphere.  Two cheap rejects keep lanes out of the (divergent) candidate path:
         //  * behind: origin certainly outside (c + k4 = 4 (|oc|^2 - r^2) - 4 E + err > 0, the margin E inside thr4

@@ -50,6 +50,12 @@ cp gpurun_out/trace_${tag}_c2/p_kernel_stats.csv $out/kernel_stats_c2_cornell.cs
 bash scripts/trace_config.sh ${tag}_c5 C5 > $out/c5_level_times.txt
 bash scripts/pmc_config.sh ${tag}_c5_sq C5 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
 cp gpurun_out/pmc_${tag}_c5_sq.json $out/pmc_sq_c5_s20k.json
+# where a wave's cycles go: parked at s_waitcnt / issue stalls / issuing (SQ_WAIT_ANY + SQ_WAIT_INST_ANY + SQ_ACTIVE_INST_ANY ~ SQ_WAVE_CYCLES)
+bash scripts/r3_wait_pass.sh ${tag} > $out/wave_cycles.txt
+cp gpurun_out/pmc_${tag}_wait.json $out/pmc_wave_cycles.json
+cp gpurun_out/pmc_${tag}_c5_wait.json $out/pmc_wave_cycles_c5_s20k.json
+# shares of a wave's time by phase and the walk's counters (diagnostic build with shader-clock stamps)
+CFTRT_STAMPS=1 CFTRT_LIB=$PWD/ray-tracing_amd/csrc/libcftrt_stamps.so python3 scripts/bench_configs.py C3 C2 C5 2> $out/stamps.txt > /dev/null
 python3 scripts/bench_configs.py C1 C2 C2p C3 C5 C4 > $out/configs.jsonl
 # one rank's share of the strong-scaling frame (64 spp split over N), and the timeline of the N = 8 share
 python3 scripts/strong_share.py > $out/strong_share.txt
