@@ -156,6 +156,13 @@ int cftrt_ctx_set_shards(cftrt_ctx* ctx, int on);
  * exists for that comparison and for profiling.  Not used by cftrt_render_device_static (it would allocate) nor by
  * the split pipeline. */
 int cftrt_ctx_set_tile_lists(cftrt_ctx* ctx, int on);
+/* The grid in LDS (default on): in a scene of spheres only whose grid - cell records and sphere entries - fits in
+ * 43 KB (S500: 35 KB), the trace levels that walk the grid with at least `above` rays (0 keeps the current value,
+ * default 2^20) run a kernel instance that first copies the grid into the CU's LDS and reads it from there: the
+ * walk is a chain of dependent, divergent loads, and through the vector memory path its waves wait most of the
+ * time.  Same cells, same entries, same tests: same image bit for bit; the switch exists for that comparison and
+ * for profiling. */
+int cftrt_ctx_set_lds_grid(cftrt_ctx* ctx, int on, uint32_t above);
 /* Deep levels path by path (default on): once fewer than `below` rays are alive (0 keeps the current value,
  * default 2^20; the host looks every 4 levels) the remaining trace levels run in one launch in which every lane
  * follows one path to its end (k_trace_finish) instead of one launch per level.  Same image bit for bit; the switch

@@ -351,7 +351,8 @@ class Device:
         self._worlds = weakref.WeakSet()   # worlds with a scene on this ctx: destroyed before the ctx
         # what the switches are set to (the C ABI has setters only): settings() / restore() for callers that change
         # them for a while
-        self._set = {"pipeline": 0, "wave_cull": 1, "grid": 1, "tile_lists": 1, "shards": 1, "finish": (1, 1 << 20), "variant": 0}
+        self._set = {"pipeline": 0, "wave_cull": 1, "grid": 1, "tile_lists": 1, "shards": 1, "finish": (1, 1 << 20), "variant": 0,
+                     "lds_grid": (1, 1 << 20)}
 
     def settings(self):
         return dict(self._set)
@@ -359,7 +360,7 @@ class Device:
     def restore(self, st):
         self.set_pipeline(st["pipeline"]); self.set_wave_cull(st["wave_cull"]); self.set_grid(st["grid"])
         self.set_tile_lists(st["tile_lists"]); self.set_shards(st["shards"]); self.set_finish(*st["finish"])
-        self.set_variant(st["variant"])
+        self.set_variant(st["variant"]); self.set_lds_grid(*st["lds_grid"])
 
     def check(self, rc):
         if rc != 0:
@@ -389,6 +390,12 @@ class Device:
         """Per-tile primitive lists for the primary rays of tiled frames (default on; same image either way)."""
         self.check(self.lib.cftrt_ctx_set_tile_lists(self.h, int(bool(on))))
         self._set["tile_lists"] = int(bool(on))
+
+    def set_lds_grid(self, on, above=0):
+        """Walk levels of sphere-only scenes whose grid fits keep it in LDS (default on, for levels of at least 2^20
+        rays); same image either way."""
+        self.check(self.lib.cftrt_ctx_set_lds_grid(self.h, int(bool(on)), int(above)))
+        self._set["lds_grid"] = (int(bool(on)), int(above) if above else self._set["lds_grid"][1])
 
     def set_shards(self, on):
         """Big trace levels append through 8 counters into a segmented queue (default on); same image either way."""

@@ -33,6 +33,8 @@ struct cftrt_ctx {
   int shards = 1;         // 1: levels with >= 2^22 rays append through CFT_SHARDS counters into a segmented queue
   int finish = 1;         // 1: once few rays are alive the remaining levels run path by path in one launch (k_trace_finish)
   uint32_t finish_below = 1u << 20;
+  int lds_grid = 1;       // 1: walk levels of sphere-only scenes whose grid fits keep it in LDS (k_trace_level<.., LISTS & 16>)
+  uint32_t lds_grid_above = 1u << 20;   // ... for levels with at least this many rays
   int tile_lists = 1;     // 1: primary rays of tiled frames scan per-tile primitive lists built per render call (k_tile_bin)
   bool tiles_active = false;   // the lists in tile_off / tile_idx are those of the render call in progress
   // what the lists in tile_off / tile_idx were built for: a render call with the same committed scene, camera and image
@@ -279,6 +281,13 @@ int cftrt_ctx_set_shards(cftrt_ctx* ctx, int on) {
 int cftrt_ctx_set_tile_lists(cftrt_ctx* ctx, int on) {
   if (!ctx) return CFTRT_ERR_INVALID;
   ctx->tile_lists = on ? 1 : 0;
+  return CFTRT_OK;
+}
+
+int cftrt_ctx_set_lds_grid(cftrt_ctx* ctx, int on, uint32_t above) {
+  if (!ctx) return CFTRT_ERR_INVALID;
+  ctx->lds_grid = on ? 1 : 0;
+  if (above) ctx->lds_grid_above = above;
   return CFTRT_OK;
 }
 
@@ -858,6 +867,24 @@ int cftrt_scene_commit(cftrt_scene* s) {
   if ((rc = upload(s, gridSph, &D.gridSph))) return rc;
   if ((rc = upload(s, gridSphX, &D.gridSphX))) return rc;
   if ((rc = upload(s, gridTri, &D.gridTri))) return rc;
+  {
+    // the sphere part of the grid as one image for the walk instances that keep it in LDS (scene_dev.h): only when
+    // it fits and no cell lists a triangle
+    bool tri_entries = false;
+    for (const uint2& c : gridCell) tri_entries = tri_entries || ((c.y >> 4) & 255u) != 0u;
+    const size_t nent = gridSph.size(), ncell = gridCell.size();
+    const size_t bytes = (nent * 24 + ncell * 8 + 15) & ~(size_t)15;
+    if (G.n[0] > 0 && !tri_entries && bytes <= (size_t)CFT_LDS_GRID_BYTES) {
+      std::vector<uint4> img(bytes / 16, make_uint4(0u, 0u, 0u, 0u));
+      unsigned char* b = (unsigned char*)img.data();
+      memcpy(b, gridSph.data(), nent * 16);
+      memcpy(b + nent * 16, gridCell.data(), ncell * 8);
+      memcpy(b + nent * 16 + ncell * 8, gridSphX.data(), nent * 8);
+      if ((rc = upload(s, img, &D.gridImg))) return rc;
+      D.gridImgBytes = (uint32_t)bytes;
+      D.gridImgEnt = (uint32_t)nent;
+    }
+  }
   if (boundF.empty()) boundF.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
   if ((rc = upload(s, boundF, &D.boundF))) return rc;
   D.tile_off = nullptr;
@@ -1092,7 +1119,12 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
 #undef CFT_TAIL
     return;
   }
-  const uint32_t g = grid_for(ctx, ((uint64_t)P + R - 1) / R, 8u);   // 8 blocks a CU (4 and 16/32 measured slower, r03)
+  // Sphere-only scenes whose grid image fits in LDS (S500: 35 KB): the big walk levels run the instance that keeps the
+  // grid there - one 1024-thread block per CU, 3 rays per lane (kernels.h, k_trace_level).
+  const bool ldsg = !gen && lean && !two_scans && !ctx->variant && S.grid_mode && S.gridImg && ctx->lds_grid && P >= ctx->lds_grid_above;
+  if (ldsg) R = 3;
+  const uint32_t g = ldsg ? (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)P + 3071) / 3072, (uint64_t)ctx->n_cu))
+                          : grid_for(ctx, ((uint64_t)P + R - 1) / R, 8u);   // 8 blocks a CU (4 and 16/32 measured slower, r03)
   const GenArgs no_gen{};
   // (experiments: unused dynamic LDS per block lowers the number of resident blocks per CU)
   static const uint32_t dyn_lds = getenv("CFTRT_EXTRA_LDS") ? (uint32_t)atoi(getenv("CFTRT_EXTRA_LDS")) : 0u;
@@ -1131,7 +1163,8 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
   const bool walk = S.grid_mode && (level > 0 || (S.grid_mode == 2 && !tiles));
   // (no moving spheres, but triangles - cornell, S20k: without the moving-sphere code the pack spills half as much)
   const bool no_msph = !S.n_msph && !two_scans;
-  if (walk) { if (lean) { CFT_LAUNCH_R(4) } else if (no_msph) { CFT_LAUNCH_R(6) } else { CFT_LAUNCH_R(7) } }
+  if (ldsg) hipLaunchKernelGGL((k_trace_level<3, 1, 4 | 16, false>), dim3(g), dim3(1024), dyn_lds, st, LA);
+  else if (walk) { if (lean) { CFT_LAUNCH_R(4) } else if (no_msph) { CFT_LAUNCH_R(6) } else { CFT_LAUNCH_R(7) } }
   else      { if (lean) { CFT_LAUNCH_R(0) } else if (no_msph) { CFT_LAUNCH_R(2) } else { CFT_LAUNCH_R(3) } }
 #undef CFT_LAUNCH_R
 #undef CFT_LAUNCH

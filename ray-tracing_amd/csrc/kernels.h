@@ -28,6 +28,10 @@
 #include "scene_dev.h"
 
 #define CFT_BLOCK 256
+// A thread's index inside its 256-thread group.  Every kernel here runs 256-thread blocks (the mask folds away under
+// their launch bounds) except the level-kernel instances that keep the grid in LDS: those run ONE 1024-thread block
+// per CU - four such groups, each with its own park and sort rows, sharing the one copy of the grid.
+#define CFT_TID (threadIdx.x & (CFT_BLOCK - 1u))
 #define CFTRT_MAX_LEVELS_DEV 256   // = CFTRT_MAX_LEVELS of include/cftrt.h (static_assert in cftrt.hip)
 #define CFT_SHADE_CHUNK 1024
 #ifndef CFT_SHADE_UNROLL
@@ -697,6 +701,25 @@ __device__ __forceinline__ void scan_msphere(const SceneDev& S, RayPack<R, NS>& 
 //    (ray_epilogue) - the stop needs no trust in the certificate.
 // Rays that start farther than 256 E from the scene centre are not walked: in the level kernels they go to the exact
 // f64 rescan (lo3 = 0), in the one-ray form closest_hit the wave scans the lists.
+// LISTS & 16 (walk instances of sphere-only scenes whose grid fits, k_trace_level): the grid's cell records and sphere
+// entries are read from a copy in LDS.  A walk is a chain of dependent, divergent loads - cell record -> entries ->
+// (16 r^2, index) of the entries that pass - and through the vector memory path each link is a round trip of several
+// hundred cycles during which the lane's wave is parked (rocprofv3: 60 % of the wave cycles of the walk instances,
+// VALU busy 0.65 at four waves per SIMD); from LDS a link costs tens of cycles.
+#ifndef CFT_LDS_GRID_BYTES
+#define CFT_LDS_GRID_BYTES (43 * 1024)
+#endif
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+typedef const v4f __attribute__((address_space(3)))* l_f4p;
+typedef const float __attribute__((address_space(3)))* l_f32p;
+typedef const uint32_t __attribute__((address_space(3)))* l_u32p;
+struct LdsGrid {
+  l_f4p sph;     // sphere entries
+  l_u32p cell;   // cell records (2 words each)
+  l_f32p x;      // (16 r^2, list index bits) per entry (2 words each)
+};
+#define CFT_NO_LDS_GRID LdsGrid{nullptr, nullptr, nullptr}
+
 #ifndef CFT_WALK_ALWAYS
 #define CFT_WALK_ALWAYS 2
 #endif
@@ -707,8 +730,21 @@ __device__ __forceinline__ void scan_msphere(const SceneDev& S, RayPack<R, NS>& 
 #define CFT_WALK_BATCH 2   // sphere entries of a cell tested per round of loads (measured: 2 beats 1 and 4 on S500 and S20k)
 #endif
 template <int R, int NS, int LISTS>
-__device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>& P, int r) {
+__device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>& P, int r, const LdsGrid lg = CFT_NO_LDS_GRID) {
   const float inf = __builtin_inff();
+  constexpr bool LDSG = (LISTS & 16) != 0;
+  auto cell_at = [&](uint32_t i) -> uint2 {
+    if constexpr (LDSG) return make_uint2(lg.cell[2u * i], lg.cell[2u * i + 1u]);   // (one ds_read_b64)
+    else return S.gridCell[i];
+  };
+  auto sph_at = [&](uint32_t e) -> float4 {
+    if constexpr (LDSG) { const v4f a = lg.sph[e]; return make_float4(a[0], a[1], a[2], a[3]); }
+    else return S.gridSph[e];
+  };
+  auto sphx_at = [&](uint32_t e) -> float2 {
+    if constexpr (LDSG) return make_float2(lg.x[2u * e], lg.x[2u * e + 1u]);
+    else return S.gridSphX[e];
+  };
   // entries per round of loads: a one-ray pack (the instances that park the others) leaves registers for more
   constexpr int NB = R == 1 ? CFT_WALK_BATCH_PARKED : CFT_WALK_BATCH;
   const float dx = PK(P, dx, r), dy = PK(P, dy, r), dz = PK(P, dz, r);
@@ -749,8 +785,7 @@ __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>&
   // to the next cell does not depend on what the current cell holds, so the next record is requested before the
   // current cell's entries are tested and its latency hides under them (a wave has one ray per lane in flight and a
   // SIMD four such waves: the dependent record -> entries loads were what the walk waited for).
-  const uint2* cells = S.gridCell;
-  uint2 cell = cells[__umul24(__umul24((uint32_t)cz, (uint32_t)S.gny) + (uint32_t)cy, (uint32_t)S.gnx) + (uint32_t)cx];   // < 2^21
+  uint2 cell = cell_at(__umul24(__umul24((uint32_t)cz, (uint32_t)S.gny) + (uint32_t)cy, (uint32_t)S.gnx) + (uint32_t)cx);   // < 2^21
 #ifdef CFT_STAMPS
   uint32_t wk_cells = 0, wk_tests = 0, wk_pass = 0;
   // how many lanes are in each part of the loop when the wave runs it: executions are counted by the first active lane
@@ -771,7 +806,7 @@ __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>&
     const bool inside = (unsigned)cx < (unsigned)S.gnx && (unsigned)cy < (unsigned)S.gny && (unsigned)cz < (unsigned)S.gnz;
     uint2 next = make_uint2(0u, 0u);
     if (inside && tnr <= tendr)
-      next = cells[__umul24(__umul24((uint32_t)cz, (uint32_t)S.gny) + (uint32_t)cy, (uint32_t)S.gnx) + (uint32_t)cx];
+      next = cell_at(__umul24(__umul24((uint32_t)cz, (uint32_t)S.gny) + (uint32_t)cy, (uint32_t)S.gnx) + (uint32_t)cx);
     // The cell's sphere entries, NB at a time: the 16 B loads of a batch are in flight together (one after
     // the other they are a chain of dependent round trips: a cell of a 20 k-primitive scene holds up to 19 entries),
     // the cull of each is 8 FMAs, and only entries that pass go on to the (rare, divergent) candidate path.  A cell
@@ -785,8 +820,8 @@ __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>&
       for (int j = 0; j < NB; ++j) {
         // the first two of a batch are loaded whatever the cell holds (clamped repeats); the others only by lanes whose
         // cell has that many entries left (a divergent load costs the texture path by its active lanes)
-        if (j < CFT_WALK_ALWAYS) a4[j] = S.gridSph[min(e0 + (uint32_t)j, ee - 1u)];
-        else if (e0 + (uint32_t)j < ee) a4[j] = S.gridSph[e0 + (uint32_t)j];
+        if (j < CFT_WALK_ALWAYS) a4[j] = sph_at(min(e0 + (uint32_t)j, ee - 1u));
+        else if (e0 + (uint32_t)j < ee) a4[j] = sph_at(e0 + (uint32_t)j);
         else a4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
       uint32_t pass = 0u;
@@ -810,8 +845,8 @@ __device__ __forceinline__ void grid_walk_ray(const SceneDev& S, RayPack<R, NS>&
 #endif
         const uint32_t e = e0 + (uint32_t)__builtin_ctz(pass);
         pass &= pass - 1u;
-        const float4 a = S.gridSph[e];    // (again: the batch sits in registers under a constant index only)
-        const float2 b = S.gridSphX[e];   // (16 r^2, list index)
+        const float4 a = sph_at(e);    // (again: the batch sits in registers under a constant index only)
+        const float2 b = sphx_at(e);   // (16 r^2, list index)
         const int idx = __float_as_int(b.y);
         bool seen = true;
 #pragma unroll
@@ -975,7 +1010,7 @@ template <int R, int NS> __device__ __forceinline__ void isect_park(const RayPac
 template <int NS> struct ParkLayout {
   static constexpr int CAND = 3, WORD = 3 + 5 * NS, WORDS = (4 + 6 * NS) > 9 ? (3 + 6 * NS) : 9;
 };
-#define PARK(r, j) park[(r) * ParkLayout<NS>::WORDS + (j)][threadIdx.x]
+#define PARK(r, j) park[(r) * ParkLayout<NS>::WORDS + (j)][CFT_TID]
 
 // f32 scan of every non-precise primitive for R rays (indices into [sphF | msph | triF | mtri]).
 // part / nparts (wave-uniform): this wave scans the part-th slice of each list (nparts = 1: all of it).
@@ -987,7 +1022,7 @@ template <int NS> struct ParkLayout {
 // list stands for the static / moving spheres and static triangles.
 template <int R, int NS, bool WCULL = false, int LISTS = 3>
 __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P, int part = 0, int nparts = 1, int tile = -1,
-                                           float (*park)[CFT_BLOCK] = nullptr) {
+                                           float (*park)[CFT_BLOCK] = nullptr, const LdsGrid lg = CFT_NO_LDS_GRID) {
   const int n4_all = (S.n_sphF + 3) >> 2;
   const int lo4 = n4_all * part / nparts, hi4 = n4_all * (part + 1) / nparts;
   Bundle B = {};
@@ -1071,7 +1106,7 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P,
               Q.c[k][0].i1 = __float_as_int(PARK(r, ParkLayout<NS>::CAND + 5 * k + 3));
               Q.c[k][0].i2 = __float_as_int(PARK(r, ParkLayout<NS>::CAND + 5 * k + 4));
             }
-            grid_walk_ray<1, NS, LISTS>(S, Q, 0);
+            grid_walk_ray<1, NS, LISTS>(S, Q, 0, lg);
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
               PARK(r, ParkLayout<NS>::CAND + 5 * k + 0) = Q.c[k][0].lo1;
@@ -1091,7 +1126,7 @@ __device__ __forceinline__ void scan_lists(const SceneDev& S, RayPack<R, NS>& P,
 #pragma unroll
           for (int k = 0; k < NS; ++k) P.c[k][r].lo3 = 0.0f;   // too far out for the walk's error bounds: rescan
         } else {
-          grid_walk_ray<R, NS, LISTS>(S, P, r);
+          grid_walk_ray<R, NS, LISTS>(S, P, r, lg);
         }
       }
     return;
@@ -1674,7 +1709,7 @@ __device__ __forceinline__ void isect_setup(const SceneDev& S, const QueueDev& q
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     // (with perm, base is the wave's first ray)
-    const uint32_t i = perm ? (perm[r][threadIdx.x] == 0xFFFFu ? 0xFFFFFFFFu : base + perm[r][threadIdx.x]) : base + r * stride;
+    const uint32_t i = perm ? (perm[r][CFT_TID] == 0xFFFFu ? 0xFFFFFFFFu : base + perm[r][CFT_TID]) : base + r * stride;
     float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 1.f;
     Closest pre;
     pre.t = __builtin_inf(); pre.g = -1;
@@ -2175,10 +2210,10 @@ template <int R> struct SortStore<R, false> {};
 template <int R>
 __device__ __forceinline__ void wave_sort_rays(const SceneDev& S, const QueueDev& q, uint32_t n, uint32_t base,
                                                uint16_t (*perm)[CFT_BLOCK], uint32_t (*hist)[32]) {
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, col0 = threadIdx.x & ~63u;
+  const uint32_t lane = threadIdx.x & 63u, wave = CFT_TID >> 6, col0 = CFT_TID & ~63u;
   if (lane < 32u) hist[wave][lane] = 0u;
 #pragma unroll
-  for (int r = 0; r < R; ++r) perm[r][threadIdx.x] = (uint16_t)0xFFFFu;
+  for (int r = 0; r < R; ++r) perm[r][CFT_TID] = (uint16_t)0xFFFFu;
   __builtin_amdgcn_wave_barrier();
   uint32_t key[R];
 #pragma unroll
@@ -2257,13 +2292,32 @@ __device__ __forceinline__ const T& kernel_args() {   // (the kernel's one param
 }
 __device__ __forceinline__ const LevelArgs& level_args() { return kernel_args<LevelArgs>(); }
 
+// LISTS & 16 (with & 4; sphere-only scenes whose grid image fits CFT_LDS_GRID_BYTES): the instance runs as ONE block
+// of 1024 threads per CU - the same 16 waves as four 256-thread blocks, each 256-thread group with its own park and
+// sort rows - and the block first copies the grid image into LDS, which every walk then reads instead of the vector
+// memory path (grid_walk_ray).  R = 3 there: 4 x 27 KB of park + 8 KB of sort rows leave 43 KB for the grid.
 template <int R, int NS, int LISTS, bool GEN = false>
-__global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(LevelArgs) {
-  __shared__ float park[ParkLayout<NS>::WORDS * R][CFT_BLOCK];
+__global__ __launch_bounds__((LISTS & 16) ? 1024 : CFT_BLOCK, 4) void k_trace_level(LevelArgs) {
+  constexpr uint32_t BLK = (LISTS & 16) ? 1024u : (uint32_t)CFT_BLOCK;
+  __shared__ float park_[BLK / CFT_BLOCK][ParkLayout<NS>::WORDS * R][CFT_BLOCK];
+  float (*const park)[CFT_BLOCK] = park_[threadIdx.x / CFT_BLOCK];
   // (the 4-ray instances serve the primary rays, which are not sorted; their park already fills the 40 KB a block
   // may take at 4 blocks per CU)
   constexpr bool SORT = (LISTS & 4) != 0 && NS == 1;   // (two-scan instances: measured slower, they spill)
-  __shared__ SortStore<R, SORT> ss;
+  __shared__ SortStore<R, SORT> ss_[BLK / CFT_BLOCK];
+  SortStore<R, SORT>& ss = ss_[threadIdx.x / CFT_BLOCK];
+  LdsGrid lg = CFT_NO_LDS_GRID;
+  if constexpr ((LISTS & 16) != 0) {
+    __shared__ uint4 lgrid[CFT_LDS_GRID_BYTES / 16];
+    const LevelArgs& A = level_args();
+    const uint32_t n16 = A.S.gridImgBytes >> 4;   // (the host launches this instance only when the image fits)
+    for (uint32_t i = threadIdx.x; i < n16; i += BLK) lgrid[i] = A.S.gridImg[i];
+    const uint32_t ncell = (uint32_t)(A.S.gnx * A.S.gny * A.S.gnz);
+    lg.sph = (l_f4p)&lgrid[0];
+    lg.cell = (l_u32p)&lgrid[0] + 4u * A.S.gridImgEnt;
+    lg.x = (l_f32p)&lgrid[0] + 4u * A.S.gridImgEnt + 2u * ncell;
+    __syncthreads();
+  }
   // The input queue: CFT_SHARDS segments of stride in_D (a dense queue: segment 0 only).  A trip takes 64 R slots of
   // ONE segment; trips are numbered through the segments in turn.  The survivors of trip `it` go to output segment
   // it mod out_k (out_k = 1: dense), which therefore receives at most ceil(trips / out_k) * 64 R rays <= out_D.
@@ -2282,12 +2336,12 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(LevelArgs) {
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t n = 0;   // slots of the current trip's segment
   auto slot_index = [&](int r, uint32_t base) -> uint32_t {
-    if constexpr (SORT) return ss.perm[r][threadIdx.x] == 0xFFFFu ? 0xFFFFFFFFu : base - (threadIdx.x & 63u) + ss.perm[r][threadIdx.x];
+    if constexpr (SORT) return ss.perm[r][CFT_TID] == 0xFFFFu ? 0xFFFFFFFFu : base - (threadIdx.x & 63u) + ss.perm[r][CFT_TID];
     else return base + r * 64u < n ? base + r * 64u : 0xFFFFFFFFu;
   };
   CFT_STAMP_DECL;
-  for (uint32_t it = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (CFT_BLOCK / 64u) + (threadIdx.x >> 6)));
-       it < trips_to[CFT_SHARDS]; it += gridDim.x * (CFT_BLOCK / 64u)) {
+  for (uint32_t it = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (BLK / 64u) + (threadIdx.x >> 6)));
+       it < trips_to[CFT_SHARDS]; it += gridDim.x * (BLK / 64u)) {
     uint32_t seg = 0;
 #pragma unroll
     for (int sh = 1; sh < CFT_SHARDS; ++sh) seg += it >= trips_to[sh] ? 1u : 0u;
@@ -2328,7 +2382,7 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(LevelArgs) {
           wave_sort_rays<R>(S, q, n, base, ss.perm, ss.hist);
         } else {
 #pragma unroll
-          for (int r = 0; r < R; ++r) ss.perm[r][threadIdx.x] = base + r * stride < n ? (uint16_t)(lane + r * stride) : (uint16_t)0xFFFFu;
+          for (int r = 0; r < R; ++r) ss.perm[r][CFT_TID] = base + r * stride < n ? (uint16_t)(lane + r * stride) : (uint16_t)0xFFFFu;
         }
       }
       CFT_STAMP(1);
@@ -2366,7 +2420,7 @@ __global__ __launch_bounds__(CFT_BLOCK, 4) void k_trace_level(LevelArgs) {
         int tile = -1;   // level 0 of a tiled frame with per-tile lists: the trip's 64 R slots are pixels of one 32x8 tile
         if constexpr (GEN && (LISTS & 4) == 0 && 256 % (64 * R) == 0)
           if (S2.tile_off && A2.gen.tiled) tile = (int)((wb % (A2.gen.cam.width * A2.gen.cam.height)) >> 8);
-        scan_lists<R, NS, (LISTS & 4) == 0, (LISTS & 4) ? (LISTS | 8) : LISTS>(S2, P, 0, 1, tile, park);
+        scan_lists<R, NS, (LISTS & 4) == 0, (LISTS & 4) ? (LISTS | 8) : LISTS>(S2, P, 0, 1, tile, park, lg);
       }
       CFT_STAMP(3);
       if constexpr (!((LISTS & 4) != 0 && CFT_PARKED_WALK(LISTS, R))) isect_park<R, NS>(P, park);   // (those walk instances park on their way)

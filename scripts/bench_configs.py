@@ -1,6 +1,6 @@
 """Runs BASELINE.json's five configs on one GPU (and the CPU restatement on C1/C2/C3-sample) and prints one
 JSON object per config.  Not the driver's bench (bench.py is); fills the table in BASELINE.md §4."""
-import importlib, json, os, sys, time
+import hashlib, importlib, json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -23,7 +23,8 @@ def gpu(name, world, cam, W, H, spp, depth, reps=2):
              mrays_per_s=st.rays / st.ms_total / 1e3, intersect_ms=st.ms_intersect, shade_ms=st.ms_shade,
              shadow_ms=st.ms_shadow, intersect_tflops=st.flops_intersect / st.ms_intersect / 1e9,
              pct_fp32_peak=st.flops_intersect / st.ms_intersect / 1e9 / 157.3 * 100, levels=int(st.levels),
-             exact_second=int(st.exact_second), exact_rescan=int(st.exact_rescan), mean_rgb=[float(x) for x in acc.astype(np.float64).mean(axis=(0, 1)) / spp])
+             exact_second=int(st.exact_second), exact_rescan=int(st.exact_rescan),
+             image_sha1=hashlib.sha1(np.ascontiguousarray(acc).tobytes()).hexdigest()[:16], mean_rgb=[float(x) for x in acc.astype(np.float64).mean(axis=(0, 1)) / spp])
     print(json.dumps(r), flush=True)
     return r
 
@@ -45,6 +46,9 @@ if os.environ.get("CFTRT_TILE_LISTS"):
 if os.environ.get("CFTRT_FINISH"):        # "on[,below]"
     f = os.environ["CFTRT_FINISH"].split(",")
     rt.default_device().set_finish(int(f[0]), int(f[1]) if len(f) > 1 else 0)
+if os.environ.get("CFTRT_LDS_GRID"):      # "on[,above]"
+    f = os.environ["CFTRT_LDS_GRID"].split(",")
+    rt.default_device().set_lds_grid(int(f[0]), int(f[1]) if len(f) > 1 else 0)
 if os.environ.get("CFTRT_VARIANT"):
     rt.default_device().set_variant(int(os.environ["CFTRT_VARIANT"]))
 which = sys.argv[1:] or ["C1", "C2", "C2p", "C3", "C4", "C5", "cpu"]
