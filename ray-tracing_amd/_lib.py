@@ -61,6 +61,7 @@ SYMBOLS = [
     ("cftrt_ctx_set_shards", C.c_int, [_P, C.c_int]),
     ("cftrt_ctx_set_tile_lists", C.c_int, [_P, C.c_int]),
     ("cftrt_ctx_set_lds_grid", C.c_int, [_P, C.c_int, C.c_uint32]),
+    ("cftrt_ctx_set_walk_classes", C.c_int, [_P, C.c_int, C.c_uint32, C.c_uint32]),
     ("cftrt_scene_create", C.c_int, [_P, C.POINTER(_P)]),
     ("cftrt_scene_destroy", None, [_P]),
     ("cftrt_scene_set_spheres", C.c_int, [_P, _D, _D, _D, _I, _I, C.c_int64]),

@@ -352,7 +352,7 @@ class Device:
         # what the switches are set to (the C ABI has setters only): settings() / restore() for callers that change
         # them for a while
         self._set = {"pipeline": 0, "wave_cull": 1, "grid": 1, "tile_lists": 1, "shards": 1, "finish": (1, 1 << 20), "variant": 0,
-                     "lds_grid": (1, 1 << 20)}
+                     "lds_grid": (1, 1 << 20), "walk_classes": (1, 0, 1 << 18)}
 
     def settings(self):
         return dict(self._set)
@@ -361,6 +361,7 @@ class Device:
         self.set_pipeline(st["pipeline"]); self.set_wave_cull(st["wave_cull"]); self.set_grid(st["grid"])
         self.set_tile_lists(st["tile_lists"]); self.set_shards(st["shards"]); self.set_finish(*st["finish"])
         self.set_variant(st["variant"]); self.set_lds_grid(*st["lds_grid"])
+        self.set_walk_classes(*st["walk_classes"])
 
     def check(self, rc):
         if rc != 0:
@@ -396,6 +397,12 @@ class Device:
         rays); same image either way."""
         self.check(self.lib.cftrt_ctx_set_lds_grid(self.h, int(bool(on)), int(above)))
         self._set["lds_grid"] = (int(bool(on)), int(above) if above else self._set["lds_grid"][1])
+
+    def set_walk_classes(self, mode, cells=0, above=0):
+        """Survivors queued in two classes by the length of their next grid walk: 0 never, 1 (default) in scenes of more
+        than 4096 primitives, 2 always; cells = 0: threshold from the grid's size.  Same image with any mode."""
+        self.check(self.lib.cftrt_ctx_set_walk_classes(self.h, int(mode), int(cells), int(above)))
+        self._set["walk_classes"] = (int(mode), int(cells), int(above) if above else self._set["walk_classes"][2])
 
     def set_shards(self, on):
         """Big trace levels append through 8 counters into a segmented queue (default on); same image either way."""

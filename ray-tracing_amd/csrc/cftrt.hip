@@ -33,6 +33,8 @@ struct cftrt_ctx {
   int shards = 1;         // 1: levels with >= 2^22 rays append through CFT_SHARDS counters into a segmented queue
   int finish = 1;         // 1: once few rays are alive the remaining levels run path by path in one launch (k_trace_finish)
   uint32_t finish_below = 1u << 20;
+  int classes = 1;        // levels whose successor walks the grid append their survivors in two classes by walk length (kernels.h, CFT_NSEG): 0 never, 1 in scenes with long lists, 2 always
+  uint32_t classes_above = 1u << 18, classes_thr = 0;   // ... for levels with at least this many rays; threshold in cells (0: from the grid's size)
   int lds_grid = 1;       // 1: walk levels of sphere-only scenes whose grid fits keep it in LDS (k_trace_level<.., LISTS & 16>)
   uint32_t lds_grid_above = 1u << 20;   // ... for levels with at least this many rays
   int tile_lists = 1;     // 1: primary rays of tiled frames scan per-tile primitive lists built per render call (k_tile_bin)
@@ -212,7 +214,7 @@ int cftrt_ctx_create(int device, cftrt_ctx** out) {
   (void)hipEventCreate(&ctx->ev_t1);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
-  if ((e = hipHostMalloc((void**)&ctx->host_counts, (size_t)CFT_SHARDS * CFT_SHARD_STRIDE * sizeof(uint32_t))) != hipSuccess) {
+  if ((e = hipHostMalloc((void**)&ctx->host_counts, (size_t)CFT_NSEG * CFT_SHARD_STRIDE * sizeof(uint32_t))) != hipSuccess) {
     g_create_error = std::string("hipHostMalloc: ") + hipGetErrorString(e);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -281,6 +283,15 @@ int cftrt_ctx_set_shards(cftrt_ctx* ctx, int on) {
 int cftrt_ctx_set_tile_lists(cftrt_ctx* ctx, int on) {
   if (!ctx) return CFTRT_ERR_INVALID;
   ctx->tile_lists = on ? 1 : 0;
+  return CFTRT_OK;
+}
+
+int cftrt_ctx_set_walk_classes(cftrt_ctx* ctx, int mode, uint32_t cells, uint32_t above) {
+  if (!ctx) return CFTRT_ERR_INVALID;
+  if (mode < 0 || mode > 2) return fail(ctx, CFTRT_ERR_INVALID, "walk classes: mode must be 0, 1 or 2");
+  ctx->classes = mode;
+  ctx->classes_thr = cells;
+  if (above) ctx->classes_above = above;
   return CFTRT_OK;
 }
 
@@ -1093,7 +1104,7 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
                                uint32_t max_depth, uint64_t pid_base, uint32_t k0, uint32_t k1, bool two_scans,
                                uint32_t role0, uint32_t role1, QueueDev qout, Rad3* rad, PhongQueueDev pq,
                                uint32_t* phong_counts, uint32_t* xstats, uint32_t P, const GenArgs* gen, uint32_t in_D,
-                               uint32_t* out_D_io, double* dbg_t = nullptr, int32_t* dbg_prim = nullptr) {
+                               uint32_t* out_D_io, double* dbg_t = nullptr, int32_t* dbg_prim = nullptr, uint32_t cls_thr = 0) {
   // *out_D_io on entry: nonzero = the caller wants the output queue sharded; on return: the segment stride used (0: dense)
   const bool want_shards = *out_D_io != 0;
   *out_D_io = 0;
@@ -1132,13 +1143,17 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
   // receives the survivors of every 8th trip
   uint32_t out_k = 1, out_D = 0;
   if (want_shards) {
-    const uint64_t trips = ((uint64_t)P + 64u * R - 1) / (64u * R) + CFT_SHARDS;
+    const uint64_t trips = ((uint64_t)P + 64u * R - 1) / (64u * R) + CFT_NSEG;
     out_k = CFT_SHARDS;
     out_D = (uint32_t)((trips + CFT_SHARDS - 1) / CFT_SHARDS) * 64u * R;
     *out_D_io = out_D;
+  } else if (cls_thr) {
+    // one segment with both classes: the short rays from slot 0 upwards, the long ones from slot out_D downwards
+    out_D = (uint32_t)std::min<uint64_t>(((uint64_t)P + 64u * R - 1) / (64u * R) * (64u * R), 0xFFFFFF00ull);
+    *out_D_io = out_D;
   }
   LevelArgs LA{S, q, counts, level, max_depth, pid_base, k0, k1, role0, role1, qout, rad, pq, phong_counts, xstats,
-               gen ? *gen : no_gen, in_D, out_k, out_D, dbg_t, dbg_prim};
+               gen ? *gen : no_gen, in_D, out_k, out_D, cls_thr, dbg_t, dbg_prim};
 #define CFT_LAUNCH(RR, NN, LL)                                                                                          \
   do {                                                                                                                  \
     if (gen) hipLaunchKernelGGL((k_trace_level<RR, NN, LL, true>), dim3(g), dim3(CFT_BLOCK), dyn_lds, st, LA);           \
@@ -1168,6 +1183,13 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
   else      { if (lean) { CFT_LAUNCH_R(0) } else if (no_msph) { CFT_LAUNCH_R(2) } else { CFT_LAUNCH_R(3) } }
 #undef CFT_LAUNCH_R
 #undef CFT_LAUNCH
+}
+
+// Survivors whose next ray crosses at least this many cells of the grid's box form the long class of the queue.
+static uint32_t walk_class_threshold(const cftrt_ctx* ctx, const SceneDev& S) {
+  if (ctx->classes_thr) return ctx->classes_thr;
+  const int t = (S.gnx + S.gny + S.gnz) / 16;
+  return (uint32_t)std::max(3, std::min(t, 16));
 }
 
 enum { CLS_GEN = 0, CLS_ISECT, CLS_SHADE, CLS_SHADOW, CLS_RESOLVE, CLS_N };
@@ -1219,7 +1241,7 @@ struct EvTimer {
   }
 };
 
-static const size_t kQueueSlack = (size_t)CFT_SHARDS * 2 * 64 * 4 + 256;   // slots a sharded queue may need beyond the ray count
+static const size_t kQueueSlack = (size_t)CFT_NSEG * 2 * 64 * 4 + 256;   // slots a sharded queue may need beyond the ray count
 // Device buffers of one pass (P paths): the ray queues, the radiance slots, the Phong queue, the level counters.
 struct PassBufs {
   QueueDev q[2];
@@ -1231,7 +1253,7 @@ struct PassBufs {
 };
 static const size_t kShardWords = 2 * CFTRT_MAX_LEVELS + 8 + 128 + 2 + 4 * 64;   // (+ walk counters of the diagnostic build)   // used words of shard 0's block
 static_assert(kShardWords <= CFT_SHARD_STRIDE, "shard 0's counters, statistics and stamps must fit its block");
-static const size_t kCountWords = (size_t)CFT_SHARDS * CFT_SHARD_STRIDE;   // shard s of level l: word s * CFT_SHARD_STRIDE + l; the rest in shard 0's block:   // (+ 64 stamp sums of 64 bits of the diagnostic build)
+static const size_t kCountWords = (size_t)CFT_NSEG * CFT_SHARD_STRIDE;   // shard s of level l: word s * CFT_SHARD_STRIDE + l; the rest in shard 0's block:   // (+ 64 stamp sums of 64 bits of the diagnostic build)
 static const size_t kStampWord = 2 * CFTRT_MAX_LEVELS + 2 + 8;   // even: 8-byte aligned behind a 256-byte aligned base
 static_assert(kStampWord % 2 == 0, "stamp sums are 64-bit words");   // [0..L] level counts, [L+1..2L+1] phong counts, then: second evaluations, rescans, k_trace_finish's queue cursor
 static_assert(CFTRT_MAX_LEVELS == CFTRT_MAX_LEVELS_DEV, "kernels.h and cftrt.h disagree on the level limit");
@@ -1442,8 +1464,13 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
       if (tm.begin(CLS_ISECT)) return fail(ctx, CFTRT_ERR_HIP, "hipEventCreate failed");   // booked as the intersect class (ms_shade stays 0)
       // big levels append through CFT_SHARDS counters (one counter takes ~88 appends per microsecond)
       uint32_t out_D = (ctx->shards && ub >= (1u << 22) && level + 1 < max_depth) ? 1u : 0u;
+      // survivors in two classes by the length of their next walk, when the next level walks the grid (kernels.h, CFT_NSEG)
+      // (mode 1: scenes with long lists only - where a walk crosses 7 cells on average and 50 at worst; S500's walks, 1.9
+      // cells, gain as much at the next level as the class key costs at this one)
+      const bool cls_scene = ctx->classes == 2 || (ctx->classes == 1 && S.n_sphF + S.n_msph + S.n_triF > promote_above);
+      const uint32_t cls_thr = (S.grid_mode && cls_scene && !ctx->variant && ub >= ctx->classes_above && level + 1 < max_depth) ? walk_class_threshold(ctx, S) : 0u;
       launch_trace_level(ctx, S, q[in], counts, level, max_depth, pid_base, k0, k1, two_scans, two_scans ? looked_role : nl, nl,
-                         q[outq], rad, pq, phong_counts, xstats, ub, level == 0 ? &gen : nullptr, in_D, &out_D);
+                         q[outq], rad, pq, phong_counts, xstats, ub, level == 0 ? &gen : nullptr, in_D, &out_D, nullptr, nullptr, cls_thr);
       in_D = out_D;
     } else {
       tm.begin(CLS_ISECT);
@@ -1469,11 +1496,11 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
     if ((level & (ub < (1u << 19) ? 15u : 3u)) == 3u && level + 1 < max_depth) {
       tm.flush();
       // (one word per shard of the next level's count)
-      HIP_TRY(ctx, hipMemcpy2DAsync(ctx->host_counts, 4, counts + level + 1, CFT_SHARD_STRIDE * 4, 4, CFT_SHARDS, hipMemcpyDeviceToHost, st_));
+      HIP_TRY(ctx, hipMemcpy2DAsync(ctx->host_counts, 4, counts + level + 1, CFT_SHARD_STRIDE * 4, 4, CFT_NSEG, hipMemcpyDeviceToHost, st_));
       HIP_TRY(ctx, hipStreamSynchronize(st_));
       {
         uint64_t live = 0;
-        for (int sh = 0; sh < CFT_SHARDS; ++sh) live += ctx->host_counts[sh];
+        for (int sh = 0; sh < CFT_NSEG; ++sh) live += ctx->host_counts[sh];
         ctx->host_counts[0] = (uint32_t)live;
       }
       if (ctx->host_counts[0] == 0) break;
@@ -1503,7 +1530,7 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
     const uint32_t* hc = ctx->host_counts;
     const uint32_t* hp = hc + CFTRT_MAX_LEVELS + 1;
     for (uint32_t l = 0; l < levels_run && l < CFTRT_MAX_LEVELS; ++l) {
-      for (int sh = 1; sh < CFT_SHARDS; ++sh) ctx->host_counts[l] += ctx->host_counts[sh * CFT_SHARD_STRIDE + l];
+      for (int sh = 1; sh < CFT_NSEG; ++sh) ctx->host_counts[l] += ctx->host_counts[sh * CFT_SHARD_STRIDE + l];
       st->rays_per_level[l] += hc[l];
       st->rays += hc[l];
       uint64_t pr = (uint64_t)hp[l] * (uint64_t)S.n_lights;
@@ -1536,6 +1563,15 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
       }
     }
 #endif
+    if (getenv("CFTRT_DEBUG")) {   // rays of the long class per level / all rays of the level
+      fprintf(stderr, "cftrt long-class rays per level:");
+      for (uint32_t l = 0; l < levels_run && l < 12; ++l) {
+        uint64_t lg = 0;
+        for (int sh = CFT_SHARDS; sh < CFT_NSEG; ++sh) lg += ctx->host_counts[sh * CFT_SHARD_STRIDE + l];
+        fprintf(stderr, " %llu/%u", (unsigned long long)lg, hc[l]);
+      }
+      fprintf(stderr, "\n");
+    }
     st->exact_second += hc[2 * CFTRT_MAX_LEVELS + 2];
     st->exact_rescan += hc[2 * CFTRT_MAX_LEVELS + 3];
     st->paths += P;

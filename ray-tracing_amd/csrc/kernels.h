@@ -66,6 +66,20 @@ static __device__ unsigned long long* g_walk_stats = nullptr;   // (diagnostic b
 // counts[s * CFT_SHARD_STRIDE + l]; a dense queue is the case where only segment 0 is filled.
 #define CFT_SHARDS 8
 #define CFT_SHARD_STRIDE 1024   // words between the counter blocks of two shards (separate cache lines and channels)
+// Two CLASSES of rays per segment (LevelArgs::cls_thr): a level kernel that walks the grid runs each slot of a wave as
+// long as the slot's longest walk, so the few rays that cross many cells hold up the waves they are scattered over
+// (S500: 8 % of the bounce rays cross four cells or more, and nearly every wave of 256 holds some).  The producing
+// level therefore appends survivors whose next ray will cross at least cls_thr cells of the grid's box ("long",
+// walk_key) from the TOP of its segment downwards and the others from the bottom up - both fit whatever the split,
+// so the queue needs no more memory - and the consuming launch takes the long segments' trips first, in waves that
+// hold nothing else.  Counter block s < CFT_SHARDS: short rays of segment s (and every ray of a queue without
+// classes); block CFT_SHARDS + s: its long rays.  The order of the queue never affects the image.
+#define CFT_NSEG (2 * CFT_SHARDS)
+// Trip order t = 0 .. CFT_NSEG - 1 (long segments first): counter block and first slot of the part, D = segment stride
+__device__ __forceinline__ uint32_t seg_block(uint32_t t) { return t < CFT_SHARDS ? t + CFT_SHARDS : t - CFT_SHARDS; }
+__device__ __forceinline__ size_t seg_first_slot(uint32_t t, uint32_t D, uint32_t count) {
+  return t < CFT_SHARDS ? (size_t)t * D + (D - count) : (size_t)(t - CFT_SHARDS) * D;
+}
 
 // constant-address-space views: a wave-uniform index then compiles to s_load (SGPR operands)
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -2278,6 +2292,7 @@ struct LevelArgs {
   uint32_t* stats;
   GenArgs gen;
   uint32_t in_D, out_k, out_D;
+  uint32_t cls_thr;   // > 0: survivors whose next ray crosses at least this many cells go to the long class (CFT_NSEG above)
   // parity hook (cftrt_level_hits; null in every render call): the winner of each scan of each ray as this kernel found
   // it, by local path id - exact distance dbg_t[NS lp + k], global prim id dbg_prim[NS lp + k] (-1: miss)
   double* dbg_t;
@@ -2321,13 +2336,13 @@ __global__ __launch_bounds__((LISTS & 16) ? 1024 : CFT_BLOCK, 4) void k_trace_le
   // The input queue: CFT_SHARDS segments of stride in_D (a dense queue: segment 0 only).  A trip takes 64 R slots of
   // ONE segment; trips are numbered through the segments in turn.  The survivors of trip `it` go to output segment
   // it mod out_k (out_k = 1: dense), which therefore receives at most ceil(trips / out_k) * 64 R rays <= out_D.
-  uint32_t trips_to[CFT_SHARDS + 1];
+  uint32_t trips_to[CFT_NSEG + 1];
   trips_to[0] = 0u;
   {
     const LevelArgs& A = level_args();
 #pragma unroll
-    for (int sh = 0; sh < CFT_SHARDS; ++sh)
-      trips_to[sh + 1] = trips_to[sh] + (AS_CONST(const uint32_t __attribute__((address_space(4)))*, A.counts)[sh * CFT_SHARD_STRIDE + A.level] + 64u * R - 1u) / (64u * R);
+    for (int sh = 0; sh < CFT_NSEG; ++sh)
+      trips_to[sh + 1] = trips_to[sh] + (AS_CONST(const uint32_t __attribute__((address_space(4)))*, A.counts)[seg_block((uint32_t)sh) * CFT_SHARD_STRIDE + A.level] + 64u * R - 1u) / (64u * R);
 #ifdef CFT_STAMPS
     if (threadIdx.x == 0 && blockIdx.x == 0) g_walk_stats = A.level < 4u ? (unsigned long long*)(A.stats + 8 + 128 + 2) + 32 * A.level : nullptr;
 #endif
@@ -2341,13 +2356,13 @@ __global__ __launch_bounds__((LISTS & 16) ? 1024 : CFT_BLOCK, 4) void k_trace_le
   };
   CFT_STAMP_DECL;
   for (uint32_t it = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (BLK / 64u) + (threadIdx.x >> 6)));
-       it < trips_to[CFT_SHARDS]; it += gridDim.x * (BLK / 64u)) {
+       it < trips_to[CFT_NSEG]; it += gridDim.x * (BLK / 64u)) {
     uint32_t seg = 0;
 #pragma unroll
-    for (int sh = 1; sh < CFT_SHARDS; ++sh) seg += it >= trips_to[sh] ? 1u : 0u;
+    for (int sh = 1; sh < CFT_NSEG; ++sh) seg += it >= trips_to[sh] ? 1u : 0u;
     uint32_t seg_trip0 = 0;
 #pragma unroll
-    for (int sh = 1; sh < CFT_SHARDS; ++sh) seg_trip0 = seg == (uint32_t)sh ? trips_to[sh] : seg_trip0;
+    for (int sh = 1; sh < CFT_NSEG; ++sh) seg_trip0 = seg == (uint32_t)sh ? trips_to[sh] : seg_trip0;
     const uint32_t wb = (it - seg_trip0) * 64u * R;
     const uint32_t base = wb + lane;
     QueueDev q;   // the trip's segment of the input queue, indexed from 0
@@ -2363,8 +2378,8 @@ __global__ __launch_bounds__((LISTS & 16) ? 1024 : CFT_BLOCK, 4) void k_trace_le
       // ---- the rays of the trip: (generated,) sorted, set up, scanned, parked
       const LevelArgs& A = level_args();
       const SceneDev& S = A.S;
-      n = AS_CONST(const uint32_t __attribute__((address_space(4)))*, A.counts)[seg * CFT_SHARD_STRIDE + A.level];
-      const size_t qoff = (size_t)seg * A.in_D;
+      n = AS_CONST(const uint32_t __attribute__((address_space(4)))*, A.counts)[seg_block(seg) * CFT_SHARD_STRIDE + A.level];
+      const size_t qoff = seg_first_slot(seg, A.in_D, n);
       q = QueueDev{A.q.a + qoff, A.q.b + qoff, A.q.c + qoff};
       CFT_STAMP(7);   // (loop overhead, and the time before the first trip)
       if constexpr (GEN && SORT) {
@@ -2426,7 +2441,7 @@ __global__ __launch_bounds__((LISTS & 16) ? 1024 : CFT_BLOCK, 4) void k_trace_le
       if constexpr (!((LISTS & 4) != 0 && CFT_PARKED_WALK(LISTS, R))) isect_park<R, NS>(P, park);   // (those walk instances park on their way)
     }
     CFT_STAMP(4);
-    uint32_t alive_bits = 0;
+    uint32_t alive_bits = 0, long_bits = 0;
     {
       // ---- the slots one by one: exact evaluation, hit record, shading
       const LevelArgs& A = level_args();
@@ -2469,6 +2484,8 @@ __global__ __launch_bounds__((LISTS & 16) ? 1024 : CFT_BLOCK, 4) void k_trace_le
                                              A.max_depth, A.pid_base, A.k0, A.k1, A.radiance, A.pq, A.phong_counts, &npos, &ndir);
         if (alive) {   // the survivor takes over the slot's park words (path id: re-read from the queue below)
           alive_bits |= 1u << r;
+          if (A.cls_thr != 0u && walk_key(S, make_float4(npos.x, npos.y, npos.z, ndir.x), make_float4(ndir.y, ndir.z, 0.f, 0.f)) >= A.cls_thr)
+            long_bits |= 1u << r;
           PARK(r, 0) = npos.x; PARK(r, 1) = npos.y; PARK(r, 2) = npos.z; PARK(r, 3) = ndir.x;
           PARK(r, 4) = ndir.y; PARK(r, 5) = ndir.z; PARK(r, 6) = thr.x;  PARK(r, 7) = thr.y;
           PARK(r, 8) = thr.z;
@@ -2485,17 +2502,29 @@ __global__ __launch_bounds__((LISTS & 16) ? 1024 : CFT_BLOCK, 4) void k_trace_le
       const LevelArgs& A = level_args();
       const QueueDev qout = A.qout;
       const uint32_t leader = (uint32_t)__ffsll((long long)__ballot(1)) - 1u;
-      uint32_t wbase = 0;
+      uint32_t wbase = 0, lbase = 0;
       const uint32_t oseg = A.out_k > 1u ? it % A.out_k : 0u;
-      if (lane == leader) wbase = atomicAdd(&A.counts[oseg * CFT_SHARD_STRIDE + A.level + 1], total);
+      // the long class (none unless cls_thr is set): reserved from the top of the segment downwards
+      uint32_t ltotal = 0;
+      if (A.cls_thr != 0u) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) ltotal += (uint32_t)__popcll(__ballot((long_bits >> r) & 1u));
+      }
+      if (lane == leader) {
+        if (total != ltotal) wbase = atomicAdd(&A.counts[oseg * CFT_SHARD_STRIDE + A.level + 1], total - ltotal);
+        if (ltotal) lbase = atomicAdd(&A.counts[(CFT_SHARDS + oseg) * CFT_SHARD_STRIDE + A.level + 1], ltotal);
+      }
       wbase = __shfl(wbase, (int)leader) + oseg * A.out_D;
+      lbase = oseg * A.out_D + A.out_D - __shfl(lbase, (int)leader) - ltotal;
       // The survivor's path id is re-read from the input queue (a dependent load per slot) - except at level 0 (lp_known)
       // (the R path-id loads issued together ahead of an unrolled loop: slower, S500 17.8 -> 18.5 ms)
 #pragma unroll 1
       for (int r = 0; r < R; ++r) {
-        const unsigned long long m = __ballot((alive_bits >> r) & 1u);
+        const bool lng = ((long_bits >> r) & 1u) != 0u;
+        const unsigned long long ml = __ballot(lng);
+        const unsigned long long m = __ballot((alive_bits >> r) & 1u) & ~ml;
         if ((alive_bits >> r) & 1u) {
-          const uint32_t o = wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+          const uint32_t o = lng ? lbase + (uint32_t)__popcll(ml & ((1ull << lane) - 1ull)) : wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
           qout.a[o] = make_float4(PARK(r, 0), PARK(r, 1), PARK(r, 2), PARK(r, 3));
           qout.b[o] = make_float4(PARK(r, 4), PARK(r, 5), PARK(r, 6), PARK(r, 7));
           float pidw;
@@ -2507,6 +2536,7 @@ __global__ __launch_bounds__((LISTS & 16) ? 1024 : CFT_BLOCK, 4) void k_trace_le
           qout.c[o] = make_float2(PARK(r, 8), pidw);
         }
         wbase += (uint32_t)__popcll(m);
+        lbase += (uint32_t)__popcll(ml);
       }
     }
     CFT_STAMP(6);
@@ -2658,11 +2688,12 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_trace_finish(FinishArgs) {
   const uint32_t level0 = A0.level0, in_D = A0.in_D;
   const QueueDev q = A0.q;
   // the input queue may be sharded: slot v of the concatenated segments sits at seg * in_D + (v - slots before seg)
-  uint32_t slots_to[CFT_SHARDS + 1];
+  // (the segments' parts in trip order, CFT_NSEG above)
+  uint32_t slots_to[CFT_NSEG + 1];
   slots_to[0] = 0u;
 #pragma unroll
-  for (int sh = 0; sh < CFT_SHARDS; ++sh) slots_to[sh + 1] = slots_to[sh] + counts[sh * CFT_SHARD_STRIDE + level0];
-  const uint32_t n = slots_to[CFT_SHARDS];
+  for (int sh = 0; sh < CFT_NSEG; ++sh) slots_to[sh + 1] = slots_to[sh] + counts[seg_block((uint32_t)sh) * CFT_SHARD_STRIDE + level0];
+  const uint32_t n = slots_to[CFT_NSEG];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   for (uint32_t l = lane; l < CFTRT_MAX_LEVELS_DEV; l += 64u) hist[wave][l] = 0u;
   __builtin_amdgcn_wave_barrier();
@@ -2682,9 +2713,11 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_trace_finish(FinishArgs) {
         if (!have) {
           const uint32_t v = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
           if (v < n) {
-            uint32_t i = v;
+            size_t i = v;
 #pragma unroll
-            for (int sh = 1; sh < CFT_SHARDS; ++sh) i += v >= slots_to[sh] ? in_D - (slots_to[sh] - slots_to[sh - 1]) : 0u;
+            for (int sh = 0; sh < CFT_NSEG; ++sh)
+              if (v >= slots_to[sh] && v < slots_to[sh + 1])
+                i = seg_first_slot((uint32_t)sh, in_D, slots_to[sh + 1] - slots_to[sh]) + (v - slots_to[sh]);
             const float4 a = q.a[i], b = q.b[i];
             const float2 c = q.c[i];
             pos = mk3(a.x, a.y, a.z); dir = mk3(a.w, b.x, b.y); thr = mk3(b.z, b.w, c.x);

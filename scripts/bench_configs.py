@@ -49,6 +49,9 @@ if os.environ.get("CFTRT_FINISH"):        # "on[,below]"
 if os.environ.get("CFTRT_LDS_GRID"):      # "on[,above]"
     f = os.environ["CFTRT_LDS_GRID"].split(",")
     rt.default_device().set_lds_grid(int(f[0]), int(f[1]) if len(f) > 1 else 0)
+if os.environ.get("CFTRT_CLASSES"):       # "on[,cells[,above]]"
+    f = [int(x) for x in os.environ["CFTRT_CLASSES"].split(",")] + [0, 0]
+    rt.default_device().set_walk_classes(f[0], f[1], f[2])
 if os.environ.get("CFTRT_VARIANT"):
     rt.default_device().set_variant(int(os.environ["CFTRT_VARIANT"]))
 which = sys.argv[1:] or ["C1", "C2", "C2p", "C3", "C4", "C5", "cpu"]

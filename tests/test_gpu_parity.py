@@ -319,6 +319,22 @@ def test_level_kernel_hits_s500(rt, orc, variant):
         dev.set_variant(0); dev.set_wave_cull(True); dev.set_grid(1)
 
 
+def test_level_kernel_hits_lds_grid_instance(rt, orc):
+    """The walk instance that keeps the grid in LDS (k_trace_level<3, 1, 4 | 16>: one 1024-thread block per CU; S500's grid
+    fits) against the oracle, hit by hit: incoherent rays from inside the scene at a bounce level, few enough to leave
+    most waves of a block without a trip and enough to give every wave several."""
+    world, cam = rt.scenes.s500()
+    ow = orc.OracleWorld(world)
+    dev = rt.default_device()
+    try:
+        dev.set_lds_grid(1, 1)       # (the default keeps the instance for levels of 2^20 rays and more)
+        for n, level in ((1500, 1), (150000, 1), (400000, 2)):
+            rays = _incoherent_rays(np.random.default_rng(n), n, -12, 12, 0.0005, 2.5)
+            assert _check_level_hits(world, ow, rays, level=level) > 0.3 * n
+    finally:
+        dev.set_lds_grid(1, 1 << 20)
+
+
 def test_level_kernel_hits_generated_primaries(rt, orc):
     """Level 0 as the render calls run it: the launch generates its own rays in 32x8-pixel tiles and scans per-tile
     lists (S500, S20k) - hits by path id against the oracle on the rays cftrt_generate returns for the same ids."""
@@ -1215,4 +1231,32 @@ def test_tile_lists_are_exact(rt):
             assert int(s2.passes) > 1, name
 
 
-
+@pytest.mark.parametrize("name,W,H,spp,depth", [("s500", 1920, 1080, 3, 12), ("scene_rs", 416, 256, 4, 10),
+                                                 ("s20k", 1920, 1080, 3, 12), ("cornell_rs", 256, 192, 4, 8)])
+def test_lds_grid_and_walk_classes_are_exact(rt, name, W, H, spp, depth):
+    """Two things that only change WHERE a ray is traced: the walk instance that reads the grid from LDS (sphere-only
+    scenes whose grid fits: S500) and the two classes of the ray queue (survivors with long next walks appended from
+    the top of each segment, taken first by the next launch; forced on here for every scene and every level size, with
+    two thresholds, sharded and dense queues).  Same image, same rays per level, same exact-evaluation counts, bit for
+    bit; scenes the features do not apply to (moving spheres, triangles: no LDS instance) run as before."""
+    dev = rt.default_device()
+    world, cam = rt.scenes.cornell_rs() if name == "cornell_rs" else getattr(rt.scenes, name)(width=W, height=H)
+    cam = cam.with_sample_rate(spp)      # (the 1080p frames: levels of more than 2^22 rays append through the 8 shards)
+    res = []
+    try:
+        dev.set_lds_grid(0); dev.set_walk_classes(0)
+        res.append(world.render(cam, W, H, depth, return_stats=True))
+        dev.set_lds_grid(1, 1)
+        res.append(world.render(cam, W, H, depth, return_stats=True))
+        for cells in (0, 2, 7):
+            dev.set_walk_classes(2, cells, 1)
+            res.append(world.render(cam, W, H, depth, return_stats=True))
+        dev.set_lds_grid(0); dev.set_shards(0)
+        res.append(world.render(cam, W, H, depth, return_stats=True))
+    finally:
+        dev.set_lds_grid(1, 1 << 20); dev.set_walk_classes(1, 0, 1 << 18); dev.set_shards(1)
+    a0, s0 = res[0]
+    for a, st in res[1:]:
+        assert np.array_equal(a0, a), name
+        assert list(s0.rays_per_level[:depth]) == list(st.rays_per_level[:depth]), name
+        assert int(s0.exact_second) == int(st.exact_second) and int(s0.exact_rescan) == int(st.exact_rescan), name
