@@ -1512,7 +1512,13 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
         const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)ub + CFT_BLOCK - 1) / CFT_BLOCK, (uint64_t)ctx->n_cu * 8));
         const FinishArgs FA{S, q[outq], counts, level + 1, max_depth, pid_base, k0, k1, two_scans ? looked_role : nl, nl,
                             two_scans ? 1 : 0, rad, xstats + 2, xstats, in_D};
-        hipLaunchKernelGGL(k_trace_finish, dim3(blocks), dim3(CFT_BLOCK), 0, st_, FA);
+        // the instance by scene kind, as for the level kernels: with a grid every ray of these (bounce) levels walks it
+        const bool f_lean = !S.n_msph && !S.n_triF && !S.n_mtri, f_no_msph = !S.n_msph && !two_scans;
+        if (!S.grid_mode) hipLaunchKernelGGL(k_trace_finish<7>, dim3(blocks), dim3(CFT_BLOCK), 0, st_, FA);
+        else if (f_lean && S.gridImg && ctx->lds_grid) hipLaunchKernelGGL((k_trace_finish<4 | 8 | 16>), dim3(blocks), dim3(CFT_BLOCK), 0, st_, FA);
+        else if (f_lean) hipLaunchKernelGGL((k_trace_finish<4 | 8>), dim3(blocks), dim3(CFT_BLOCK), 0, st_, FA);
+        else if (f_no_msph) hipLaunchKernelGGL((k_trace_finish<6 | 8>), dim3(blocks), dim3(CFT_BLOCK), 0, st_, FA);
+        else hipLaunchKernelGGL((k_trace_finish<7 | 8>), dim3(blocks), dim3(CFT_BLOCK), 0, st_, FA);
         levels_run = max_depth;
         break;
       }

@@ -1413,16 +1413,19 @@ __device__ __forceinline__ Closest ray_epilogue(const SceneDev& S, float ox, flo
   return r;
 }
 
-// Ray::hit for one ray (used by the parity hook and the shadow kernel).
+// Ray::hit for one ray (used by the parity hook, the shadow kernel and k_trace_finish).  LISTS as in scan_lists: 7 = every
+// path (cone cull aside: one ray is no bundle), chosen at run time; with 8 the caller guarantees a grid and the ray walks it.
+template <int LISTS = 7>
 __device__ __forceinline__ Closest closest_hit(const SceneDev& S, float ox, float oy, float oz, float dx,
-                                               float dy, float dz, uint32_t scan_word, uint32_t* stats) {
+                                               float dy, float dz, uint32_t scan_word, uint32_t* stats,
+                                               const LdsGrid lg = CFT_NO_LDS_GRID) {
   RayPack<1, 1> P;
   P.word[0][0] = scan_word;
   cand_init(P.c[0][0]);
   Closest pre = precise_hit(S, ox, oy, oz, dx, dy, dz, scan_word);
   ray_setup<1, 1>(S, P, 0, ox, oy, oz, dx, dy, dz, pre);
   pack_dummy_slot<1, 1>(P, 1);
-  scan_lists<1, 1, false, 7>(S, P);
+  scan_lists<1, 1, false, LISTS>(S, P, 0, 1, -1, nullptr, lg);
   return ray_epilogue(S, ox, oy, oz, dx, dy, dz, scan_word, P.c[0][0], pre, stats);
 }
 
@@ -2681,8 +2684,28 @@ struct FinishArgs {   // (one struct, read per phase through the kernarg pointer
   uint32_t* stats;
   uint32_t in_D;
 };
-__global__ __launch_bounds__(CFT_BLOCK) void k_trace_finish(FinishArgs) {
+// LISTS: what the one-ray scans may need (scan_lists): 7 = everything, decided at run time (grid off, or any scene);
+// with 8 the scene has a grid and every ray walks it - instances without the list-scan code, and without the
+// moving-sphere / triangle code where the scene has none, keep fewer registers (more resident waves: the kernel waits
+// on latency, not on issue); with 16 the walks read the grid from LDS (k_trace_level).
+#ifndef CFT_FINISH_WAVES
+#define CFT_FINISH_WAVES 3   // (measured: S20k 44.5 -> 43.7 ms at 3 waves per SIMD, 168 VGPRs, a few spills; 4 spills 190 B per lane for the same time; S500 unchanged)
+#endif
+template <int LISTS>
+__global__ __launch_bounds__(CFT_BLOCK, (LISTS & 8) ? CFT_FINISH_WAVES : 2) void k_trace_finish(FinishArgs) {
   __shared__ uint32_t hist[CFT_BLOCK / 64][CFTRT_MAX_LEVELS_DEV];
+  LdsGrid lg = CFT_NO_LDS_GRID;
+  if constexpr ((LISTS & 16) != 0) {
+    __shared__ uint4 lgrid[CFT_LDS_GRID_BYTES / 16];
+    const FinishArgs& A = kernel_args<FinishArgs>();
+    const uint32_t n16 = A.S.gridImgBytes >> 4;
+    for (uint32_t i = threadIdx.x; i < n16; i += CFT_BLOCK) lgrid[i] = A.S.gridImg[i];
+    const uint32_t ncell = (uint32_t)(A.S.gnx * A.S.gny * A.S.gnz);
+    lg.sph = (l_f4p)&lgrid[0];
+    lg.cell = (l_u32p)&lgrid[0] + 4u * A.S.gridImgEnt;
+    lg.x = (l_f32p)&lgrid[0] + 4u * A.S.gridImgEnt + 2u * ncell;
+    __syncthreads();
+  }
   const FinishArgs& A0 = kernel_args<FinishArgs>();
   uint32_t* const counts = A0.counts;
   const uint32_t level0 = A0.level0, in_D = A0.in_D;
@@ -2751,9 +2774,9 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_trace_finish(FinishArgs) {
         wA = philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), level, CFT_PURPOSE_SCAN0 + role0, k0, k1).x;
         wB = two_scans ? philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), level, CFT_PURPOSE_SCAN0 + role1, k0, k1).x : wA;
       }
-      const Closest cA = closest_hit(S, pos.x, pos.y, pos.z, dir.x, dir.y, dir.z, wA, stats);
+      const Closest cA = closest_hit<LISTS>(S, pos.x, pos.y, pos.z, dir.x, dir.y, dir.z, wA, stats, lg);
       Closest cB = cA;
-      if (two_scans) cB = closest_hit(S, pos.x, pos.y, pos.z, dir.x, dir.y, dir.z, wB, stats);
+      if (two_scans) cB = closest_hit<LISTS>(S, pos.x, pos.y, pos.z, dir.x, dir.y, dir.z, wB, stats, lg);
       HitInRegisters hit;
       hit.ta = cA.t;
       hit.a0 = make_float4((float)cA.t, __int_as_float(cA.g), 0.f, 0.f);
