@@ -157,7 +157,7 @@ int cftrt_ctx_set_shards(cftrt_ctx* ctx, int on);
  * the split pipeline. */
 int cftrt_ctx_set_tile_lists(cftrt_ctx* ctx, int on);
 /* The grid in LDS (default on): in a scene of spheres only whose grid - cell records and sphere entries - fits in
- * 43 KB (S500: 35 KB), the trace levels that walk the grid with at least `above` rays (0 keeps the current value,
+ * 50 KB (S500: 35 KB), the trace levels that walk the grid with at least `above` rays (0 keeps the current value,
  * default 2^20) run a kernel instance that first copies the grid into the CU's LDS and reads it from there: the
  * walk is a chain of dependent, divergent loads, and through the vector memory path its waves wait most of the
  * time.  Same cells, same entries, same tests: same image bit for bit; the switch exists for that comparison and

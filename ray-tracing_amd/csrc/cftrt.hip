@@ -1133,8 +1133,8 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
   // Sphere-only scenes whose grid image fits in LDS (S500: 35 KB): the big walk levels run the instance that keeps the
   // grid there - one 1024-thread block per CU, 3 rays per lane (kernels.h, k_trace_level).
   const bool ldsg = !gen && lean && !two_scans && !ctx->variant && S.grid_mode && S.gridImg && ctx->lds_grid && P >= ctx->lds_grid_above;
-  if (ldsg) R = 3;
-  const uint32_t g = ldsg ? (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)P + 3071) / 3072, (uint64_t)ctx->n_cu))
+  if (ldsg) R = 3;   // (2 rays per lane: 2 % slower)
+  const uint32_t g = ldsg ? (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)P + 1024 * R - 1) / (1024 * R), (uint64_t)ctx->n_cu))
                           : grid_for(ctx, ((uint64_t)P + R - 1) / R, 8u);   // 8 blocks a CU (4 and 16/32 measured slower, r03)
   const GenArgs no_gen{};
   // (experiments: unused dynamic LDS per block lowers the number of resident blocks per CU)
@@ -1515,7 +1515,6 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
         // the instance by scene kind, as for the level kernels: with a grid every ray of these (bounce) levels walks it
         const bool f_lean = !S.n_msph && !S.n_triF && !S.n_mtri, f_no_msph = !S.n_msph && !two_scans;
         if (!S.grid_mode) hipLaunchKernelGGL(k_trace_finish<7>, dim3(blocks), dim3(CFT_BLOCK), 0, st_, FA);
-        else if (f_lean && S.gridImg && ctx->lds_grid) hipLaunchKernelGGL((k_trace_finish<4 | 8 | 16>), dim3(blocks), dim3(CFT_BLOCK), 0, st_, FA);
         else if (f_lean) hipLaunchKernelGGL((k_trace_finish<4 | 8>), dim3(blocks), dim3(CFT_BLOCK), 0, st_, FA);
         else if (f_no_msph) hipLaunchKernelGGL((k_trace_finish<6 | 8>), dim3(blocks), dim3(CFT_BLOCK), 0, st_, FA);
         else hipLaunchKernelGGL((k_trace_finish<7 | 8>), dim3(blocks), dim3(CFT_BLOCK), 0, st_, FA);

@@ -721,7 +721,7 @@ __device__ __forceinline__ void scan_msphere(const SceneDev& S, RayPack<R, NS>& 
 // hundred cycles during which the lane's wave is parked (rocprofv3: 60 % of the wave cycles of the walk instances,
 // VALU busy 0.65 at four waves per SIMD); from LDS a link costs tens of cycles.
 #ifndef CFT_LDS_GRID_BYTES
-#define CFT_LDS_GRID_BYTES (43 * 1024)
+#define CFT_LDS_GRID_BYTES (50 * 1024)
 #endif
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 typedef const v4f __attribute__((address_space(3)))* l_f4p;
@@ -2311,9 +2311,9 @@ __device__ __forceinline__ const T& kernel_args() {   // (the kernel's one param
 __device__ __forceinline__ const LevelArgs& level_args() { return kernel_args<LevelArgs>(); }
 
 // LISTS & 16 (with & 4; sphere-only scenes whose grid image fits CFT_LDS_GRID_BYTES): the instance runs as ONE block
-// of 1024 threads per CU - the same 16 waves as four 256-thread blocks, each 256-thread group with its own park and
-// sort rows - and the block first copies the grid image into LDS, which every walk then reads instead of the vector
-// memory path (grid_walk_ray).  R = 3 there: 4 x 27 KB of park + 8 KB of sort rows leave 43 KB for the grid.
+// of 1024 threads per CU - the same 16 waves as four 256-thread blocks, each 256-thread group with its own park
+// rows - and the block first copies the grid image into LDS, which every walk then reads instead of the vector
+// memory path (grid_walk_ray).  R = 3 and no in-wave sort there: 4 x 27 KB of park leave 50 KB for the grid.
 template <int R, int NS, int LISTS, bool GEN = false>
 __global__ __launch_bounds__((LISTS & 16) ? 1024 : CFT_BLOCK, 4) void k_trace_level(LevelArgs) {
   constexpr uint32_t BLK = (LISTS & 16) ? 1024u : (uint32_t)CFT_BLOCK;
@@ -2321,7 +2321,9 @@ __global__ __launch_bounds__((LISTS & 16) ? 1024 : CFT_BLOCK, 4) void k_trace_le
   float (*const park)[CFT_BLOCK] = park_[threadIdx.x / CFT_BLOCK];
   // (the 4-ray instances serve the primary rays, which are not sorted; their park already fills the 40 KB a block
   // may take at 4 blocks per CU)
-  constexpr bool SORT = (LISTS & 4) != 0 && NS == 1;   // (two-scan instances: measured slower, they spill)
+  // (two-scan instances: measured slower, they spill; the instance with the grid in LDS: its walks are cheap enough
+  // that the sort no longer pays - same time with and without, and without it the sort rows' 8 KB go to the grid)
+  constexpr bool SORT = (LISTS & 4) != 0 && NS == 1 && (LISTS & 16) == 0;
   __shared__ SortStore<R, SORT> ss_[BLK / CFT_BLOCK];
   SortStore<R, SORT>& ss = ss_[threadIdx.x / CFT_BLOCK];
   LdsGrid lg = CFT_NO_LDS_GRID;
@@ -2687,25 +2689,13 @@ struct FinishArgs {   // (one struct, read per phase through the kernarg pointer
 // LISTS: what the one-ray scans may need (scan_lists): 7 = everything, decided at run time (grid off, or any scene);
 // with 8 the scene has a grid and every ray walks it - instances without the list-scan code, and without the
 // moving-sphere / triangle code where the scene has none, keep fewer registers (more resident waves: the kernel waits
-// on latency, not on issue); with 16 the walks read the grid from LDS (k_trace_level).
+// on latency, not on issue).  (An instance with the grid in LDS was no faster: the launch lasts as long as its longest path.)
 #ifndef CFT_FINISH_WAVES
 #define CFT_FINISH_WAVES 3   // (measured: S20k 44.5 -> 43.7 ms at 3 waves per SIMD, 168 VGPRs, a few spills; 4 spills 190 B per lane for the same time; S500 unchanged)
 #endif
 template <int LISTS>
 __global__ __launch_bounds__(CFT_BLOCK, (LISTS & 8) ? CFT_FINISH_WAVES : 2) void k_trace_finish(FinishArgs) {
   __shared__ uint32_t hist[CFT_BLOCK / 64][CFTRT_MAX_LEVELS_DEV];
-  LdsGrid lg = CFT_NO_LDS_GRID;
-  if constexpr ((LISTS & 16) != 0) {
-    __shared__ uint4 lgrid[CFT_LDS_GRID_BYTES / 16];
-    const FinishArgs& A = kernel_args<FinishArgs>();
-    const uint32_t n16 = A.S.gridImgBytes >> 4;
-    for (uint32_t i = threadIdx.x; i < n16; i += CFT_BLOCK) lgrid[i] = A.S.gridImg[i];
-    const uint32_t ncell = (uint32_t)(A.S.gnx * A.S.gny * A.S.gnz);
-    lg.sph = (l_f4p)&lgrid[0];
-    lg.cell = (l_u32p)&lgrid[0] + 4u * A.S.gridImgEnt;
-    lg.x = (l_f32p)&lgrid[0] + 4u * A.S.gridImgEnt + 2u * ncell;
-    __syncthreads();
-  }
   const FinishArgs& A0 = kernel_args<FinishArgs>();
   uint32_t* const counts = A0.counts;
   const uint32_t level0 = A0.level0, in_D = A0.in_D;
@@ -2774,9 +2764,9 @@ __global__ __launch_bounds__(CFT_BLOCK, (LISTS & 8) ? CFT_FINISH_WAVES : 2) void
         wA = philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), level, CFT_PURPOSE_SCAN0 + role0, k0, k1).x;
         wB = two_scans ? philox4x32_10((uint32_t)pid, (uint32_t)(pid >> 32), level, CFT_PURPOSE_SCAN0 + role1, k0, k1).x : wA;
       }
-      const Closest cA = closest_hit<LISTS>(S, pos.x, pos.y, pos.z, dir.x, dir.y, dir.z, wA, stats, lg);
+      const Closest cA = closest_hit<LISTS>(S, pos.x, pos.y, pos.z, dir.x, dir.y, dir.z, wA, stats);
       Closest cB = cA;
-      if (two_scans) cB = closest_hit<LISTS>(S, pos.x, pos.y, pos.z, dir.x, dir.y, dir.z, wB, stats, lg);
+      if (two_scans) cB = closest_hit<LISTS>(S, pos.x, pos.y, pos.z, dir.x, dir.y, dir.z, wB, stats);
       HitInRegisters hit;
       hit.ta = cA.t;
       hit.a0 = make_float4((float)cA.t, __int_as_float(cA.g), 0.f, 0.f);

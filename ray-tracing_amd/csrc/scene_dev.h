@@ -52,7 +52,7 @@ struct SceneDev {
   const float2* gridSphX; // per entry: (16 r^2, list index bits), read when the cull passes
   const uint32_t* gridTri;   // index into triItem
   // The sphere part of the grid once more as ONE image, for the walk instances that keep it in LDS (a scene whose grid
-  // fits, CFT_LDS_GRID_BYTES: S500's is 35 KB): [sphere entries, 16 B each][cell records, 8 B each][(16 r^2, list
+  // fits, CFT_LDS_GRID_BYTES = 50 KB: S500's is 35 KB): [sphere entries, 16 B each][cell records, 8 B each][(16 r^2, list
   // index), 8 B each].  Null: too big, or the cells list triangles.
   const uint4* gridImg;
   uint32_t gridImgBytes, gridImgEnt;   // size (a multiple of 16) and the number of sphere entries
