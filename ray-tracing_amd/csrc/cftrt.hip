@@ -1132,8 +1132,12 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
   }
   // Sphere-only scenes whose grid image fits in LDS (S500: 35 KB): the big walk levels run the instance that keeps the
   // grid there - one 1024-thread block per CU, 3 rays per lane (kernels.h, k_trace_level).
-  const bool ldsg = !gen && lean && !two_scans && !ctx->variant && S.grid_mode && S.gridImg && ctx->lds_grid && P >= ctx->lds_grid_above;
-  if (ldsg) R = 3;   // (2 rays per lane: 2 % slower)
+  // (also scenes with moving spheres, whose swept bounds are the grid's entries: scene.rs - two scans per level when
+  // the scene has lights, 2 rays per lane and a smaller cap then)
+  const bool spheres_only = !S.n_triF && !S.n_mtri;
+  const bool ldsg = !gen && spheres_only && !ctx->variant && S.grid_mode && S.gridImg && ctx->lds_grid && P >= ctx->lds_grid_above &&
+                    (two_scans ? S.gridImgBytes <= (uint32_t)CFT_LDS_GRID_BYTES2 : true);
+  if (ldsg) R = two_scans ? 2 : 3;   // (one scan at 2 rays per lane: 2 % slower)
   const uint32_t g = ldsg ? (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)P + 1024 * R - 1) / (1024 * R), (uint64_t)ctx->n_cu))
                           : grid_for(ctx, ((uint64_t)P + R - 1) / R, 8u);   // 8 blocks a CU (4 and 16/32 measured slower, r03)
   const GenArgs no_gen{};
@@ -1178,7 +1182,9 @@ static void launch_trace_level(cftrt_ctx* ctx, const SceneDev& S, QueueDev q, ui
   const bool walk = S.grid_mode && (level > 0 || (S.grid_mode == 2 && !tiles));
   // (no moving spheres, but triangles - cornell, S20k: without the moving-sphere code the pack spills half as much)
   const bool no_msph = !S.n_msph && !two_scans;
-  if (ldsg) hipLaunchKernelGGL((k_trace_level<3, 1, 4 | 16, false>), dim3(g), dim3(1024), dyn_lds, st, LA);
+  if (ldsg && two_scans) hipLaunchKernelGGL((k_trace_level<2, 2, 1 | 4 | 16, false>), dim3(g), dim3(1024), dyn_lds, st, LA);
+  else if (ldsg && lean) hipLaunchKernelGGL((k_trace_level<3, 1, 4 | 16, false>), dim3(g), dim3(1024), dyn_lds, st, LA);
+  else if (ldsg) hipLaunchKernelGGL((k_trace_level<3, 1, 1 | 4 | 16, false>), dim3(g), dim3(1024), dyn_lds, st, LA);
   else if (walk) { if (lean) { CFT_LAUNCH_R(4) } else if (no_msph) { CFT_LAUNCH_R(6) } else { CFT_LAUNCH_R(7) } }
   else      { if (lean) { CFT_LAUNCH_R(0) } else if (no_msph) { CFT_LAUNCH_R(2) } else { CFT_LAUNCH_R(3) } }
 #undef CFT_LAUNCH_R

@@ -721,7 +721,8 @@ __device__ __forceinline__ void scan_msphere(const SceneDev& S, RayPack<R, NS>& 
 // hundred cycles during which the lane's wave is parked (rocprofv3: 60 % of the wave cycles of the walk instances,
 // VALU busy 0.65 at four waves per SIMD); from LDS a link costs tens of cycles.
 #ifndef CFT_LDS_GRID_BYTES
-#define CFT_LDS_GRID_BYTES (50 * 1024)
+#define CFT_LDS_GRID_BYTES (50 * 1024)    // one scan per level: beside 4 x 27 KB of park (3 rays per lane)
+#define CFT_LDS_GRID_BYTES2 (38 * 1024)   // two scans per level (moving scenes with lights): beside 4 x 30 KB (2 rays per lane, 15 words each)
 #endif
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 typedef const v4f __attribute__((address_space(3)))* l_f4p;
@@ -2310,7 +2311,7 @@ __device__ __forceinline__ const T& kernel_args() {   // (the kernel's one param
 }
 __device__ __forceinline__ const LevelArgs& level_args() { return kernel_args<LevelArgs>(); }
 
-// LISTS & 16 (with & 4; sphere-only scenes whose grid image fits CFT_LDS_GRID_BYTES): the instance runs as ONE block
+// LISTS & 16 (with & 4; scenes of spheres only, static or moving, whose grid image fits CFT_LDS_GRID_BYTES): the instance runs as ONE block
 // of 1024 threads per CU - the same 16 waves as four 256-thread blocks, each 256-thread group with its own park
 // rows - and the block first copies the grid image into LDS, which every walk then reads instead of the vector
 // memory path (grid_walk_ray).  R = 3 and no in-wave sort there: 4 x 27 KB of park leave 50 KB for the grid.
@@ -2328,7 +2329,7 @@ __global__ __launch_bounds__((LISTS & 16) ? 1024 : CFT_BLOCK, 4) void k_trace_le
   SortStore<R, SORT>& ss = ss_[threadIdx.x / CFT_BLOCK];
   LdsGrid lg = CFT_NO_LDS_GRID;
   if constexpr ((LISTS & 16) != 0) {
-    __shared__ uint4 lgrid[CFT_LDS_GRID_BYTES / 16];
+    __shared__ uint4 lgrid[(NS == 2 ? CFT_LDS_GRID_BYTES2 : CFT_LDS_GRID_BYTES) / 16];
     const LevelArgs& A = level_args();
     const uint32_t n16 = A.S.gridImgBytes >> 4;   // (the host launches this instance only when the image fits)
     for (uint32_t i = threadIdx.x; i < n16; i += BLK) lgrid[i] = A.S.gridImg[i];

@@ -320,9 +320,9 @@ def test_level_kernel_hits_s500(rt, orc, variant):
 
 
 def test_level_kernel_hits_lds_grid_instance(rt, orc):
-    """The walk instance that keeps the grid in LDS (k_trace_level<3, 1, 4 | 16>: one 1024-thread block per CU; S500's grid
-    fits) against the oracle, hit by hit: incoherent rays from inside the scene at a bounce level, few enough to leave
-    most waves of a block without a trip and enough to give every wave several."""
+    """The walk instances that keep the grid in LDS (k_trace_level<.., LISTS & 16>: one 1024-thread block per CU; the grids
+    of S500 and scene.rs fit) against the oracle, hit by hit: incoherent rays from inside the scene at a bounce level, few
+    enough to leave most waves of a block without a trip and enough to give every wave several."""
     world, cam = rt.scenes.s500()
     ow = orc.OracleWorld(world)
     dev = rt.default_device()
@@ -331,6 +331,15 @@ def test_level_kernel_hits_lds_grid_instance(rt, orc):
         for n, level in ((1500, 1), (150000, 1), (400000, 2)):
             rays = _incoherent_rays(np.random.default_rng(n), n, -12, 12, 0.0005, 2.5)
             assert _check_level_hits(world, ow, rays, level=level) > 0.3 * n
+        # scene.rs: 480 of its spheres move (the grid's entries are their swept bounds), a sky: two scans per level,
+        # each with its own motion times (<2, 2, 1 + 4 + 16>); the same objects without the light: one scan (<3, 1, 1 + 4 + 16>)
+        world, cam = rt.scenes.scene_rs()
+        rays = _incoherent_rays(np.random.default_rng(5), 120000, -12, 12, 0.0005, 2.5)
+        assert _check_level_hits(world, orc.OracleWorld(world), rays, level=1, seed=7, pid0=64) > 0.3 * len(rays)
+        dark = rt.World.empty()
+        for o in world.objects:
+            dark.add_obj(o)
+        assert _check_level_hits(dark, orc.OracleWorld(dark), rays, level=2, seed=7, pid0=64) > 0.3 * len(rays)
     finally:
         dev.set_lds_grid(1, 1 << 20)
 
