@@ -239,7 +239,7 @@ int cftrt_render_device(cftrt_scene* scene, const cftrt_camera* cam, uint32_t wi
  * file-scope device array of CFTRT_STATIC_SCRATCH_BYTES (256 MiB) that every GPU the library runs on holds until the
  * process ends; the call makes no hipMalloc/hipFree and creates no event (cftrt_stats: ms_total only, the per-kernel
  * times stay 0).  Limit: one sample of the image must fit - width*height*92 bytes (148 with PhongModel materials,
- * +40/80 in the split pipeline) <= 256 MiB less the 380 KiB the library keeps for the level counters, the slack
+ * +40/80 in the split pipeline) <= 256 MiB less the 732 KiB the library keeps for the level counters, the slack
  * of the segmented queues and the alignment of its carves (kStaticHeader + 4 KiB in cftrt.hip), i.e. up to 2.91 M
  * pixels (1920x1080 fits, 3840x2160 does not): CFTRT_ERR_LIMIT otherwise.  Larger sample counts run as several passes.  All calls on one GPU share that
  * GPU's array (whatever the ctx): calls that overlap in time on one GPU race; the library clears the counters it
