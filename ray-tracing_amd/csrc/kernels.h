@@ -2329,9 +2329,10 @@ __global__ __launch_bounds__((LISTS & 16) ? 1024 : CFT_BLOCK, 4) void k_trace_le
   SortStore<R, SORT>& ss = ss_[threadIdx.x / CFT_BLOCK];
   LdsGrid lg = CFT_NO_LDS_GRID;
   if constexpr ((LISTS & 16) != 0) {
-    __shared__ uint4 lgrid[(NS == 2 ? CFT_LDS_GRID_BYTES2 : CFT_LDS_GRID_BYTES) / 16];
+    constexpr uint32_t CAP16 = (NS == 2 ? CFT_LDS_GRID_BYTES2 : CFT_LDS_GRID_BYTES) / 16;
+    __shared__ uint4 lgrid[CAP16];
     const LevelArgs& A = level_args();
-    const uint32_t n16 = A.S.gridImgBytes >> 4;   // (the host launches this instance only when the image fits)
+    const uint32_t n16 = min(A.S.gridImgBytes >> 4, CAP16);   // (the host launches this instance only when the image fits)
     for (uint32_t i = threadIdx.x; i < n16; i += BLK) lgrid[i] = A.S.gridImg[i];
     const uint32_t ncell = (uint32_t)(A.S.gnx * A.S.gny * A.S.gnz);
     lg.sph = (l_f4p)&lgrid[0];

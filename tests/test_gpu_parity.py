@@ -1269,3 +1269,53 @@ def test_lds_grid_and_walk_classes_are_exact(rt, name, W, H, spp, depth):
         assert np.array_equal(a0, a), name
         assert list(s0.rays_per_level[:depth]) == list(st.rays_per_level[:depth]), name
         assert int(s0.exact_second) == int(st.exact_second) and int(s0.exact_rescan) == int(st.exact_rescan), name
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_lds_grid_random_sphere_worlds(rt, seed):
+    """Random worlds of spheres only - 60 to 1 400 of them from pebbles to boulders, overlapping, a negative radius,
+    every fifth one moving, with a sky (two scans per level where spheres move), a light shape, or no light at all
+    (one scan, black frames aside: the ray counts still compare), mirrors and glass - rendered with the grid read from
+    LDS and not, the queue in one class and in two: same bits.  The larger worlds' grids do not fit and take the other
+    instances, which the switch must leave alone."""
+    A = rt
+    rng = np.random.default_rng(4000 + seed)
+    mats = [A.LambertianModel(0.9).with_color((0.8, 0.6, 0.4)), A.Metal(0.0, 0.95), A.Metal(0.2, 0.9).with_color((0.9, 0.9, 1.0)),
+            A.Dielectric(1.5), A.Specular(0.9), A.Transparent(0.3, 1.3)]
+    world = A.World.empty()
+    world.add_obj(A.Object(A.Sphere((0.0, 0.0, -300.0), 300.0), mats[0]))
+    n = [60, 300, 700, 1400, 200, 500][seed - 1]
+    moving = seed % 2 == 0
+    for i in range(n):
+        c = tuple(rng.uniform(-8, 8, 2)) + (float(rng.uniform(0.0, 2.0)),)
+        r = float(rng.choice([0.05, 0.1, 0.2, 0.6]) * rng.uniform(0.5, 1.5))
+        if i == 7:
+            r = -r
+        o = A.Object(A.Sphere(c, r), mats[int(rng.integers(len(mats)))])
+        if moving and i % 5 == 0:
+            o = o.moved(tuple(rng.uniform(-0.4, 0.4, 3)))
+        world.add_obj(o)
+    if seed % 3 == 0:
+        world.add_light(A.LightShape(A.Sphere((0.0, 0.0, 6.0), 2.0)))
+    elif seed != 5:
+        world.add_light(A.SkyLight())
+    cam = (A.Camera.new((6.0, -5.0, 1.2), (0.0, 0.0, 0.5)).with_fov(55.0).with_aspect(2.0).with_aperture(0.04)
+           .with_focus_dist(7.0).with_sample_rate(4))
+    W, H, depth = 256, 128, 10
+    dev = rt.default_device()
+    res = []
+    try:
+        dev.set_lds_grid(0); dev.set_walk_classes(0)
+        res.append(world.render(cam, W, H, depth, seed=seed, return_stats=True))
+        dev.set_lds_grid(1, 1)
+        res.append(world.render(cam, W, H, depth, seed=seed, return_stats=True))
+        dev.set_walk_classes(2, 1 + seed, 1)
+        res.append(world.render(cam, W, H, depth, seed=seed, return_stats=True))
+    finally:
+        dev.set_lds_grid(1, 1 << 20); dev.set_walk_classes(1, 0, 1 << 18)
+    a0, s0 = res[0]
+    assert int(s0.rays) > W * H * 4
+    for a, st in res[1:]:
+        assert np.array_equal(a0, a), seed
+        assert list(s0.rays_per_level[:depth]) == list(st.rays_per_level[:depth]), seed
+        assert int(s0.exact_second) == int(st.exact_second) and int(s0.exact_rescan) == int(st.exact_rescan), seed
