@@ -72,12 +72,15 @@ __host__ __device__ __forceinline__ float motion_time(uint32_t scan_word, uint32
 }
 
 // util.rs:384-395 — on the sphere surface, z >= 0, not uniform (reproduced as is): theta = 2 pi u_theta,
-// phi = pi u_phi - pi/2.  The angles are multiples of pi of exact f32 numbers, so sin / cos come from sincospi (exact
-// range reduction, no large-argument path): sin(phi) = -cos(pi u_phi), cos(phi) = sin(pi u_phi).
+// phi = pi u_phi - pi/2, i.e. sin(phi) = -cos(pi u_phi), cos(phi) = sin(pi u_phi).
 __device__ __forceinline__ f3 gen_point_in_sphere(float radius, float u_theta, float u_phi) {
-  float st, ct, s1, c1;
-  sincospif(2.0f * u_theta, &st, &ct);
-  sincospif(u_phi, &s1, &c1);
+  // v_sin_f32 / v_cos_f32 take their argument in revolutions - theta = 2 pi u_theta, pi u_phi = 2 pi (u_phi / 2), both
+  // in [0, 1): no range reduction - and are good to ~1e-6 absolute: four instructions where two sincospif calls issue
+  // ~50.  The scattered direction is f32 against the reference's f64 either way (same share of paths within 1e-3 of the
+  // oracle's, tests/test_gpu_parity.py::test_per_path_radiance); once the walk's loads left the level kernels
+  // VALU-bound (round 3) this is 1-2 % of a frame.  The camera's lens sample below keeps sincospif.
+  const float st = __builtin_amdgcn_sinf(u_theta), ct = __builtin_amdgcn_cosf(u_theta);
+  const float s1 = __builtin_amdgcn_sinf(0.5f * u_phi), c1 = __builtin_amdgcn_cosf(0.5f * u_phi);
   const float sp = -c1, cp = s1;
   return f3{radius * sp * ct, radius * sp * st, radius * cp};
 }
