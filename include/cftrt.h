@@ -163,15 +163,14 @@ int cftrt_ctx_set_tile_lists(cftrt_ctx* ctx, int on);
  * time.  Same cells, same entries, same tests: same image bit for bit; the switch exists for that comparison and
  * for profiling. */
 int cftrt_ctx_set_lds_grid(cftrt_ctx* ctx, int on, uint32_t above);
-/* Two classes of rays in the queue: a wave of a level that walks the grid runs each of its ray slots as long as the
- * slot's longest walk, so a trace level with at least `above` rays (0 keeps the current value, default 2^18) whose
- * successor walks the grid appends the survivors whose next ray will cross at least `cells` cells of the grid's box
- * (0: a threshold derived from the grid's size) from the top of each queue segment downwards and the others from the
- * bottom up, and the next launch takes the long part first, in waves that hold nothing else.  No extra memory.
- *   mode 0: never;  1 (default): in scenes that list more than 4096 primitives (S20k: -4 %; in S500, whose walks
- *   cross 1.9 cells, the next level gains what the class key costs this one);  2: always.
- * Which wave traces a ray never affects the image: same image bit for bit with any mode. */
-int cftrt_ctx_set_walk_classes(cftrt_ctx* ctx, int mode, uint32_t cells, uint32_t above);
+/* Two classes of rays in the queue (default on): a wave of a level that walks the grid runs each of its ray slots as
+ * long as the slot's longest walk, so a trace level with at least `above` rays (0 keeps the current value, default
+ * 2^18) whose successor walks the grid appends the survivors whose next ray will cross at least `cells` cells of the
+ * grid's box (0: a threshold derived from the grid's size) from the top of each queue segment downwards and the
+ * others from the bottom up, and the next launch takes the long part first, in waves that hold nothing else.  No
+ * extra memory.  S500 -3.7 %, S20k -4 %.  Which wave traces a ray never affects the image: same image bit for bit;
+ * the switch exists for that comparison and for profiling. */
+int cftrt_ctx_set_walk_classes(cftrt_ctx* ctx, int on, uint32_t cells, uint32_t above);
 /* Deep levels path by path (default on): once fewer than `below` rays are alive (0 keeps the current value,
  * default 2^20; the host looks every 4 levels) the remaining trace levels run in one launch in which every lane
  * follows one path to its end (k_trace_finish) instead of one launch per level.  Same image bit for bit; the switch

@@ -398,11 +398,11 @@ class Device:
         self.check(self.lib.cftrt_ctx_set_lds_grid(self.h, int(bool(on)), int(above)))
         self._set["lds_grid"] = (int(bool(on)), int(above) if above else self._set["lds_grid"][1])
 
-    def set_walk_classes(self, mode, cells=0, above=0):
-        """Survivors queued in two classes by the length of their next grid walk: 0 never, 1 (default) in scenes of more
-        than 4096 primitives, 2 always; cells = 0: threshold from the grid's size.  Same image with any mode."""
-        self.check(self.lib.cftrt_ctx_set_walk_classes(self.h, int(mode), int(cells), int(above)))
-        self._set["walk_classes"] = (int(mode), int(cells), int(above) if above else self._set["walk_classes"][2])
+    def set_walk_classes(self, on, cells=0, above=0):
+        """Survivors queued in two classes by the length of their next grid walk (default on; cells = 0: threshold from the
+        grid's size); same image either way."""
+        self.check(self.lib.cftrt_ctx_set_walk_classes(self.h, int(bool(on)), int(cells), int(above)))
+        self._set["walk_classes"] = (int(bool(on)), int(cells), int(above) if above else self._set["walk_classes"][2])
 
     def set_shards(self, on):
         """Big trace levels append through 8 counters into a segmented queue (default on); same image either way."""

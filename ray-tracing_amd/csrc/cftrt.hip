@@ -33,7 +33,7 @@ struct cftrt_ctx {
   int shards = 1;         // 1: levels with >= 2^22 rays append through CFT_SHARDS counters into a segmented queue
   int finish = 1;         // 1: once few rays are alive the remaining levels run path by path in one launch (k_trace_finish)
   uint32_t finish_below = 1u << 20;
-  int classes = 1;        // levels whose successor walks the grid append their survivors in two classes by walk length (kernels.h, CFT_NSEG): 0 never, 1 in scenes with long lists, 2 always
+  int classes = 1;        // 1: levels whose successor walks the grid append their survivors in two classes by walk length (kernels.h, CFT_NSEG)
   uint32_t classes_above = 1u << 18, classes_thr = 0;   // ... for levels with at least this many rays; threshold in cells (0: from the grid's size)
   int lds_grid = 1;       // 1: walk levels of sphere-only scenes whose grid fits keep it in LDS (k_trace_level<.., LISTS & 16>)
   uint32_t lds_grid_above = 1u << 20;   // ... for levels with at least this many rays
@@ -286,10 +286,9 @@ int cftrt_ctx_set_tile_lists(cftrt_ctx* ctx, int on) {
   return CFTRT_OK;
 }
 
-int cftrt_ctx_set_walk_classes(cftrt_ctx* ctx, int mode, uint32_t cells, uint32_t above) {
+int cftrt_ctx_set_walk_classes(cftrt_ctx* ctx, int on, uint32_t cells, uint32_t above) {
   if (!ctx) return CFTRT_ERR_INVALID;
-  if (mode < 0 || mode > 2) return fail(ctx, CFTRT_ERR_INVALID, "walk classes: mode must be 0, 1 or 2");
-  ctx->classes = mode;
+  ctx->classes = on ? 1 : 0;
   ctx->classes_thr = cells;
   if (above) ctx->classes_above = above;
   return CFTRT_OK;
@@ -1471,10 +1470,9 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
       // big levels append through CFT_SHARDS counters (one counter takes ~88 appends per microsecond)
       uint32_t out_D = (ctx->shards && ub >= (1u << 22) && level + 1 < max_depth) ? 1u : 0u;
       // survivors in two classes by the length of their next walk, when the next level walks the grid (kernels.h, CFT_NSEG)
-      // (mode 1: scenes with long lists only - where a walk crosses 7 cells on average and 50 at worst; S500's walks, 1.9
-      // cells, gain as much at the next level as the class key costs at this one)
-      const bool cls_scene = ctx->classes == 2 || (ctx->classes == 1 && S.n_sphF + S.n_msph + S.n_triF > promote_above);
-      const uint32_t cls_thr = (S.grid_mode && cls_scene && !ctx->variant && ub >= ctx->classes_above && level + 1 < max_depth) ? walk_class_threshold(ctx, S) : 0u;
+      // (S20k -4 %; S500 -3.7 % with the instance that reads the grid from LDS and does not sort its rays - with the
+      // sorting instance the next level gained what the class key costs this one)
+      const uint32_t cls_thr = (S.grid_mode && ctx->classes && !ctx->variant && ub >= ctx->classes_above && level + 1 < max_depth) ? walk_class_threshold(ctx, S) : 0u;
       launch_trace_level(ctx, S, q[in], counts, level, max_depth, pid_base, k0, k1, two_scans, two_scans ? looked_role : nl, nl,
                          q[outq], rad, pq, phong_counts, xstats, ub, level == 0 ? &gen : nullptr, in_D, &out_D, nullptr, nullptr, cls_thr);
       in_D = out_D;

@@ -105,7 +105,7 @@ extern "C" {
     pub fn cftrt_ctx_set_shards(ctx: *mut cftrt_ctx, on: c_int) -> c_int;
     pub fn cftrt_ctx_set_tile_lists(ctx: *mut cftrt_ctx, on: c_int) -> c_int;
     pub fn cftrt_ctx_set_lds_grid(ctx: *mut cftrt_ctx, on: c_int, above: u32) -> c_int;
-    pub fn cftrt_ctx_set_walk_classes(ctx: *mut cftrt_ctx, mode: c_int, cells: u32, above: u32) -> c_int;
+    pub fn cftrt_ctx_set_walk_classes(ctx: *mut cftrt_ctx, on: c_int, cells: u32, above: u32) -> c_int;
     pub fn cftrt_ctx_set_finish(ctx: *mut cftrt_ctx, on: c_int, below: u32) -> c_int;
     pub fn cftrt_ctx_set_variant(ctx: *mut cftrt_ctx, variant: c_int) -> c_int;
     // ---- scene
