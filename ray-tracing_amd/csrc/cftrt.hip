@@ -1565,6 +1565,9 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
                   wk[0], (double)wk[1] / wk[0], (double)wk[2] / wk[0], (double)wk[3] / wk[0], (double)wk[8] / wk[0], (double)wk[9] / wk[0],
                   (double)wk[10] / wk[0], (double)wk[11] / wk[0], (double)wk[12] / wk[0], (double)wk[13] / wk[0], (double)wk[16] / wk[0],
                   (double)wk[17] / wk[0], (double)wk[18] / wk[0], (double)wk[19] / wk[0], (double)wk[20] / wk[0], (double)wk[21] / wk[0], (double)wk[22] / wk[0]);
+        if (l < 4 && wk[3])   // of the entries that reach the candidate path: robust discriminant passes, a bound results, a hit is certified
+          fprintf(stderr, "  candidate path: %.3f of its entries pass the robust discriminant, %.3f leave a bound, %.3f certify a hit\n",
+                  (double)wk[28] / wk[3], (double)wk[29] / wk[3], (double)wk[30] / wk[3]);
         if (l < 4 && wk[24])   // lanes in each part of the walk's loop, per execution by a wave
           fprintf(stderr, "  walk loop per ray slot of a wave (%.0f): step %.1f executions with %.1f lanes | batch %.1f with %.1f lanes | candidate path %.1f with %.1f lanes\n",
                   (double)hc[l] / 64.0, (double)wk[24] / ((double)hc[l] / 64.0), (double)wk[1] / (double)wk[24], (double)wk[25] / ((double)hc[l] / 64.0),

@@ -517,6 +517,13 @@ __device__ __forceinline__ void sphere_candidate(const SceneDev& S, RayPack<R, N
   if (d16 >= P.negE16[r]) {
     float thi = __builtin_inff();
     float tlo = sphere_lower_bound(S, 0.25f * q4, 0.0625f * d16, P.U[r], hi ? &thi : nullptr);
+#ifdef CFT_STAMPS
+    if (ONCE && g_walk_stats) {   // (diagnostic build: what becomes of the entries that reach the walk's candidate path)
+      atomicAdd(&g_walk_stats[28], 1ull);
+      if (tlo >= 0.0f) atomicAdd(&g_walk_stats[29], 1ull);
+      if (thi < __builtin_inff()) atomicAdd(&g_walk_stats[30], 1ull);
+    }
+#endif
     if (tlo >= 0.0f) {
 #pragma unroll
       for (int k = 0; k < NS; ++k) {
