@@ -1500,13 +1500,8 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
     if ((level & (ub < (1u << 19) ? 15u : 3u)) == 3u && level + 1 < max_depth) {
       tm.flush();
       // (one word per shard of the next level's count)
-      HIP_TRY(ctx, hipMemcpy2DAsync(ctx->host_counts, 4, counts + level + 1, CFT_SHARD_STRIDE * 4, 4, CFT_NSEG, hipMemcpyDeviceToHost, st_));
+      hipLaunchKernelGGL(k_peek, dim3(1), dim3(64), 0, st_, (const uint32_t*)(counts + level + 1), ctx->host_counts);
       HIP_TRY(ctx, hipStreamSynchronize(st_));
-      {
-        uint64_t live = 0;
-        for (int sh = 0; sh < CFT_NSEG; ++sh) live += ctx->host_counts[sh];
-        ctx->host_counts[0] = (uint32_t)live;
-      }
       if (ctx->host_counts[0] == 0) break;
       ub = ctx->host_counts[0];
       if (!split && !phong && ctx->finish && !ctx->variant && ub < ctx->finish_below) {

@@ -2888,6 +2888,19 @@ __global__ __launch_bounds__(CFT_BLOCK) void k_shadow(ShadowArgs) {
   }
 }
 
+// The host's peek at a level's ray count: the sum of the level's counter blocks (kernels.h, CFT_NSEG), written to
+// pinned host memory by one wave - the host then only waits for the stream (a strided device-to-host copy of the 16
+// words took 40 - 160 us of idle GPU per peek).
+__global__ __launch_bounds__(64) void k_peek(const uint32_t* counts_level, uint32_t* host_out) {
+  uint32_t v = threadIdx.x < (uint32_t)CFT_NSEG ? counts_level[threadIdx.x * CFT_SHARD_STRIDE] : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if (threadIdx.x == 0) {
+    *host_out = v;
+    __threadfence_system();
+  }
+}
+
 // ------------------------------------------------------------------ resolve
 // one lane = one pixel: the pass's samples are added to accum[pix] one by one, in sample order.  The running sum
 // starts from the value already there, so the result does not depend on how a call's sample range was cut into
