@@ -1499,7 +1499,7 @@ static int run_pass(cftrt_scene* s, const CamDev& C, uint64_t pid_base, uint32_t
     // next level's count; stop when the queue has drained
     if ((level & (ub < (1u << 19) ? 15u : 3u)) == 3u && level + 1 < max_depth) {
       tm.flush();
-      // (one word per shard of the next level's count)
+      // (the next level's count: the sum of its counter blocks, by one wave, into pinned memory)
       hipLaunchKernelGGL(k_peek, dim3(1), dim3(64), 0, st_, (const uint32_t*)(counts + level + 1), ctx->host_counts);
       HIP_TRY(ctx, hipStreamSynchronize(st_));
       if (ctx->host_counts[0] == 0) break;

@@ -2347,9 +2347,11 @@ __global__ __launch_bounds__((LISTS & 16) ? 1024 : CFT_BLOCK, 4) void k_trace_le
     lg.x = (l_f32p)&lgrid[0] + 4u * A.S.gridImgEnt + 2u * ncell;
     __syncthreads();
   }
-  // The input queue: CFT_SHARDS segments of stride in_D (a dense queue: segment 0 only).  A trip takes 64 R slots of
-  // ONE segment; trips are numbered through the segments in turn.  The survivors of trip `it` go to output segment
-  // it mod out_k (out_k = 1: dense), which therefore receives at most ceil(trips / out_k) * 64 R rays <= out_D.
+  // The input queue: CFT_SHARDS segments of stride in_D (a dense queue: segment 0 only), each in two parts - the long
+  // class at its top, the short class (or every ray, in a queue without classes) at its bottom (CFT_NSEG above).  A trip
+  // takes 64 R slots of ONE part; trips are numbered through the long parts, then the short ones.  The survivors of trip
+  // `it` go to output segment it mod out_k (out_k = 1: dense), which therefore receives at most
+  // ceil(trips / out_k) * 64 R rays <= out_D, whatever their split into classes.
   uint32_t trips_to[CFT_NSEG + 1];
   trips_to[0] = 0u;
   {
